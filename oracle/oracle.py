@@ -1,0 +1,227 @@
+"""ctypes front-end of the CPU oracle (oracle/mf_oracle.c) and of the real reference build (oracle/_ref).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+Nothing under recommender-system_amd/ may import this module.
+
+Reference citations for each function live in mf_oracle.c; the `Ref*` helpers call the reference's OWN
+compiled functions (matFact.c:29 matrix_factorization, mat2d.c:61 mat2d_random_fill_LR, ...) through
+oracle/_ref/libmatfact_ref.so, which oracle/Makefile builds from /root/reference where the sources lie.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_DIR = os.path.join(HERE, "_ref")
+REFERENCE_ROOT = "/root/reference"
+
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+
+def build(o3=False, ref=True):
+    """(Re)build liboracle.so (and oracle/_ref when the reference checkout is present)."""
+    targets = ["all"] + (["liboracle_o3.so"] if o3 else [])
+    if ref and os.path.isdir(REFERENCE_ROOT):
+        targets.append("ref")
+    subprocess.check_call(["make", "-s", "-C", HERE] + targets)
+
+
+_libs = {}
+
+
+def _lib(o3=False):
+    name = "liboracle_o3.so" if o3 else "liboracle.so"
+    if name not in _libs:
+        path = os.path.join(HERE, name)
+        if not os.path.exists(path):
+            build(o3=o3, ref=False)
+        lib = C.CDLL(path)
+        lib.orc_init_factors.argtypes = [C.c_int, C.c_int, C.c_int, _f64p, _f64p]
+        lib.orc_init_factors.restype = None
+        lib.orc_factorize.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, _i32p, _i32p, _f64p,
+                                      C.c_int, C.c_double, _f64p, _f64p]
+        lib.orc_factorize.restype = None
+        lib.orc_factorize_timed.argtypes = lib.orc_factorize.argtypes
+        lib.orc_factorize_timed.restype = C.c_double
+        lib.orc_factorize_omp.argtypes = lib.orc_factorize.argtypes + [C.POINTER(C.c_int)]
+        lib.orc_factorize_omp.restype = C.c_double
+        lib.orc_predict_row.argtypes = [C.c_int, C.c_int, _f64p, _f64p, _f64p]
+        lib.orc_predict_row.restype = None
+        lib.orc_recommend.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, _i32p, _i32p, _f64p, _f64p, _i32p]
+        lib.orc_recommend.restype = None
+        lib.orc_shard_step.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _i32p, _i32p, _f64p,
+                                       C.c_double, _f64p, _f64p, C.c_int, _f64p, _f64p]
+        lib.orc_shard_step.restype = None
+        _libs[name] = lib
+    return _libs[name]
+
+
+# ----------------------------------------------------------------------------- .in / .out text formats
+class Instance:
+    """A parsed `.in` file (grammar: matFact.c:79-105 via util.c:12-34): iters, alpha, K, U I nnz, triples."""
+
+    def __init__(self, iters, alpha, feats, users, items, row, col, val):
+        self.iters, self.alpha, self.feats = int(iters), float(alpha), int(feats)
+        self.users, self.items = int(users), int(items)
+        self.row = np.ascontiguousarray(row, np.int32)
+        self.col = np.ascontiguousarray(col, np.int32)
+        self.val = np.ascontiguousarray(val, np.float64)
+
+    @property
+    def nnz(self):
+        return int(self.row.shape[0])
+
+
+def parse_in(path_or_text, is_text=False):
+    """Whitespace-token parser, same acceptance as fscanf("%d"/"%lf") for well-formed files."""
+    if is_text:
+        text = path_or_text
+    else:
+        opener = open
+        if str(path_or_text).endswith(".gz"):
+            import gzip
+            opener = gzip.open
+        with opener(path_or_text, "rt") as f:
+            text = f.read()
+    tok = text.split()
+    iters, alpha, feats = int(tok[0]), float(tok[1]), int(tok[2])
+    users, items, nnz = int(tok[3]), int(tok[4]), int(tok[5])
+    body = np.array(tok[6:6 + 3 * nnz], dtype=np.float64).reshape(nnz, 3) if nnz else np.zeros((0, 3))
+    return Instance(iters, alpha, feats, users, items, body[:, 0].astype(np.int32),
+                    body[:, 1].astype(np.int32), body[:, 2])
+
+
+def format_out(best):
+    """stdout of print_output (matFact.c:24-25): one index per user that has an unrated item."""
+    return "".join("%d\n" % b for b in best if b >= 0)
+
+
+# ----------------------------------------------------------------------------- oracle entry points
+def init_factors(users, items, feats):
+    L = np.empty((users, feats), np.float64)
+    R = np.empty((items, feats), np.float64)
+    _lib().orc_init_factors(users, items, feats, L, R)
+    return L, R
+
+
+def factorize(inst, L, R, iters=None, alpha=None):
+    """In place; returns (L, R)."""
+    it = inst.iters if iters is None else iters
+    al = inst.alpha if alpha is None else alpha
+    _lib().orc_factorize(inst.users, inst.items, inst.feats, inst.nnz, inst.row, inst.col, inst.val,
+                         it, al, L, R)
+    return L, R
+
+
+def recommend(inst, L, R):
+    best = np.empty(inst.users, np.int32)
+    _lib().orc_recommend(inst.users, inst.items, inst.feats, inst.nnz, inst.row, inst.col, L, R, best)
+    return best
+
+
+def predict_row(Li, R):
+    out = np.empty(R.shape[0], np.float64)
+    _lib().orc_predict_row(R.shape[0], R.shape[1], np.ascontiguousarray(Li), R, out)
+    return out
+
+
+def shard_step(u0, users_loc, items, feats, row, col, val, alpha, L_old, R_old, r_is_root):
+    L_new = np.empty_like(L_old)
+    R_aux = np.empty_like(R_old)
+    _lib().orc_shard_step(u0, users_loc, items, feats, int(row.shape[0]), row, col, val, alpha,
+                          L_old, R_old, int(bool(r_is_root)), L_new, R_aux)
+    return L_new, R_aux
+
+
+def run(inst):
+    """Whole serial program: init, iterate, recommend."""
+    L, R = init_factors(inst.users, inst.items, inst.feats)
+    factorize(inst, L, R)
+    return L, R, recommend(inst, L, R)
+
+
+def factorize_omp(users, items, feats, row, col, val, iters, alpha, L, R, o3=True):
+    """OpenMP REDUCTION=1 port (matFact-omp.c:35-144). Sorts by column first when items > users
+    (matFact-omp.c:44-48).  Returns (seconds in the iteration loop, threads used)."""
+    if items > users:
+        order = np.lexsort((row, col))
+        row, col, val = (np.ascontiguousarray(a[order]) for a in (row, col, val))
+    nthr = C.c_int(0)
+    sec = _lib(o3).orc_factorize_omp(users, items, feats, int(row.shape[0]), row, col, val,
+                                     iters, alpha, L, R, C.byref(nthr))
+    return sec, nthr.value
+
+
+def factorize_timed(users, items, feats, row, col, val, iters, alpha, L, R, o3=True):
+    return _lib(o3).orc_factorize_timed(users, items, feats, int(row.shape[0]), row, col, val,
+                                        iters, alpha, L, R)
+
+
+# ----------------------------------------------------------------------------- the real reference
+class _Mat2d(C.Structure):  # mat2d.h:6-11
+    _fields_ = [("n_r", C.c_int), ("n_c", C.c_int), ("data", C.POINTER(C.c_double))]
+
+
+class _Entry(C.Structure):  # datatypes.h:10-15
+    _fields_ = [("row", C.c_int), ("col", C.c_int), ("value", C.c_double)]
+
+
+def ref_available():
+    return os.path.exists(os.path.join(REF_DIR, "libmatfact_ref.so"))
+
+
+def _reflib(omp=False):
+    key = "ref_omp" if omp else "ref"
+    if key not in _libs:
+        lib = C.CDLL(os.path.join(REF_DIR, "libmatfact_omp_ref.so" if omp else "libmatfact_ref.so"))
+        lib.mat2d_new.argtypes = [C.c_int, C.c_int]
+        lib.mat2d_new.restype = C.POINTER(_Mat2d)
+        lib.mat2d_free.argtypes = [C.POINTER(_Mat2d)]
+        lib.mat2d_random_fill_LR.argtypes = [C.POINTER(_Mat2d), C.POINTER(_Mat2d), C.c_double]
+        lib.mat2d_transpose.argtypes = [C.POINTER(_Mat2d), C.POINTER(_Mat2d)]
+        lib.matrix_factorization.argtypes = [C.POINTER(_Mat2d)] * 3 + [C.POINTER(_Entry), C.c_int, C.c_int,
+                                                                     C.c_double]
+        lib.matrix_factorization.restype = None
+        _libs[key] = lib
+    return _libs[key]
+
+
+def _mat_to_np(m):
+    n_r, n_c = m.contents.n_r, m.contents.n_c
+    return np.ctypeslib.as_array(m.contents.data, shape=(n_r, n_c)).copy()
+
+
+def ref_run(inst, iters=None, omp=False):
+    """Drive the REFERENCE's compiled functions exactly as its main does (matFact.c:113-124):
+    mat2d_random_fill_LR, mat2d_transpose, matrix_factorization.  Returns (L, R, B) as numpy copies."""
+    lib = _reflib(omp)
+    it = inst.iters if iters is None else iters
+    ent = (_Entry * max(inst.nnz + 1, 1))()
+    for n in range(inst.nnz):
+        ent[n].row, ent[n].col, ent[n].value = int(inst.row[n]), int(inst.col[n]), float(inst.val[n])
+    ent[inst.nnz].row = -1  # defined sentinel where the reference reads one past the end
+    L = lib.mat2d_new(inst.users, inst.feats)
+    Ri = lib.mat2d_new(inst.feats, inst.items)
+    lib.mat2d_random_fill_LR(L, Ri, float(inst.feats))
+    R = lib.mat2d_new(inst.items, inst.feats)
+    lib.mat2d_transpose(Ri, R)
+    lib.mat2d_free(Ri)
+    B = lib.mat2d_new(inst.users, inst.items)
+    lib.matrix_factorization(B, L, R, ent, inst.nnz, it, inst.alpha)
+    out = _mat_to_np(L), _mat_to_np(R), _mat_to_np(B)
+    for m in (L, R, B):
+        lib.mat2d_free(m)
+    return out
+
+
+def ref_cli(path, variant="serial", threads=None):
+    """stdout of the reference's hand-in binaries (deliverables/*): exactly the `.out` format."""
+    exe = {"serial": "matFact_serial", "omp": "matFact_omp", "omp_atomic": "matFact_omp_atomic"}[variant]
+    env = dict(os.environ)
+    if threads:
+        env["OMP_NUM_THREADS"] = str(threads)
+    return subprocess.run([os.path.join(REF_DIR, exe), path], check=True, capture_output=True, env=env,
+                          text=True).stdout
