@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- nnz-updates/s of the matrix-factorisation iteration on MI355X (BASELINE.json's metric).
+
+One "step" = one full iteration of the hot path over the whole rating matrix: the item sweep (R), the
+all-reduce of R when sharded, and the user sweep (L) -- matFact.c:36-54 / matFact-mpi.c:185-209.
+Workload at N=1: BASELINE.json configs[3] ("cfg4": synthetic 1e6 x 1e5, K=100, ~1e8 entries), the config the
+north-star target is quoted on; it fits one GPU.  For N>1 the SAME instance is row-sharded over the ranks
+(strong scaling, as the config says), one process per GPU, RCCL all-reduce of the item factor.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg4|cfg3|cfg5|twin] [--users U --items I ...]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+Inputs are resident in HBM before the timed region.  The oracle is used only for the cpu_baseline leg.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: users, items, K, min_row, max_row, alpha, seed  
+    "cfg4": dict(users=1_000_000, items=100_000, feats=100, min_row=50, max_row=150, alpha=1e-4, seed=0xC0FFEE + 4),
+    "cfg5": dict(users=1_000_000, items=1_000_000, feats=256, min_row=250, max_row=750, alpha=1e-5, seed=0xC0FFEE + 5),
+    "cfg3": dict(users=6040, items=3952, feats=100, min_row=20, max_row=311, alpha=1e-4, seed=0xC0FFEE + 3),
+    "twin": dict(users=10_000, items=1_000, feats=100, min_row=50, max_row=150, alpha=1e-4, seed=0xC0FFEE + 4),
+}
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(nnz, feats, rows_owned):
+    """A_upd(K) = 16 + 16K bytes per nnz-update over both sweeps (half per sweep launch)
+    plus the dense term 16*K bytes per owned row (read old + write new)."""
+    return nnz * (8 + 8 * feats) + 16 * feats * rows_owned
+
+
+def cpu_baseline(cfg, capi, budget_s=12.0):
+    """OpenMP port of matFact-omp.c (oracle/mf_oracle.c: orc_factorize_omp) on a bounded sample of the SAME
+    workload: the first `sample_users` users (all items, same K), loop time only."""
+    from oracle import oracle as O
+    O.build(o3=True, ref=False)
+    cores = len(os.sched_getaffinity(0))
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    sample_users = min(cfg["users"], 100_000)
+    row, col, val = capi.synth_block(cfg["seed"], cfg["users"], cfg["items"], cfg["min_row"], cfg["max_row"],
+                                     0, sample_users)
+    rng = np.random.default_rng(1)
+    K = cfg["feats"]
+    L = rng.random((sample_users, K)) / K
+    R = rng.random((cfg["items"], K)) / K
+    nnz = int(row.shape[0])
+    t0 = time.time()
+    sec, thr = O.factorize_omp(sample_users, cfg["items"], K, row, col, val, 1, cfg["alpha"], L, R, o3=True)
+    iters, total_sec, total_it = 1, sec, 1
+    while time.time() - t0 < budget_s and total_it < 50:
+        iters = max(1, min(10, int((budget_s - (time.time() - t0)) / max(sec, 1e-3) / 2)))
+        s, thr = O.factorize_omp(sample_users, cfg["items"], K, row, col, val, iters, cfg["alpha"], L, R, o3=True)
+        total_sec += s
+        total_it += iters
+        sec = s / iters
+    return {"value": nnz * total_it / total_sec, "unit": "nnz-updates/s", "cores": thr, "kind": "port",
+            "sample": "first %d users of the workload (%d entries, all %d items, K=%d), %d iterations, "
+                      "OpenMP REDUCTION=1 port of matFact-omp.c, -O3, loop time only" % (
+                          sample_users, nnz, cfg["items"], K, total_it),
+            "s_per_iter_sample": total_sec / total_it}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
+    ap.add_argument("--users", type=int)
+    ap.add_argument("--items", type=int)
+    ap.add_argument("--feats", type=int)
+    ap.add_argument("--min-row", type=int)
+    ap.add_argument("--max-row", type=int)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--partition", default="entries", choices=["entries", "rows"])
+    args = ap.parse_args()
+
+    cfg = dict(CONFIGS[args.config])
+    for k in ("users", "items", "feats", "min_row", "max_row"):
+        if getattr(args, k) is not None:
+            cfg[k] = getattr(args, k)
+
+    import torch
+    import torch.distributed as dist
+    import recommender_system_amd as rs
+    capi = rs.capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available() or capi.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    U, I, K = cfg["users"], cfg["items"], cfg["feats"]
+    # ---- this rank's block of the synthetic instance
+    t_setup = time.time()
+    counts, total_nnz = capi.synth_counts(cfg["seed"], U, I, cfg["min_row"], cfg["max_row"])
+    ptr = np.zeros(U + 1, np.int64)
+    np.cumsum(counts, out=ptr[1:])
+    begin = capi.partition_users(U, world, ptr if args.partition == "entries" else None)
+    u0, uc = int(begin[rank]), int(begin[rank + 1] - begin[rank])
+    row, col, val = capi.synth_block(cfg["seed"], U, I, cfg["min_row"], cfg["max_row"], u0, uc)
+    nnz_loc = int(row.shape[0])
+    Lb, R0 = capi.init_factors_block(U, I, K, u0, uc)     # the reference's init rule (mat2d.c:61-72)
+    r_bufs = [torch.empty(I, K, dtype=torch.float64, device=dev) for _ in range(2)]
+    plan = capi.Plan(U, I, K, cfg["alpha"], row, col, val, user_begin=u0, user_count=uc, device=local_rank,
+                     items_ext=[t.data_ptr() for t in r_bufs])
+    del row, col, val
+    stream = torch.cuda.current_stream()
+    plan.set_stream(stream.cuda_stream)
+    plan.upload(Lb, R0)
+    del Lb, R0
+    run = rs.sharded.ShardedFactorization(plan, r_bufs, rank, world, overlap=not args.no_overlap)
+    t_setup = time.time() - t_setup
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run.step()
+    fence()
+    plan.timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run.step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    plan.timing(False)
+    tm = plan.timing_read()
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    # ---- roofline of the dominant kernel (the sweep kernel; item and user sweeps are the same kernel)
+    launches = tm["item_launches"] + tm["user_launches"]
+    avg_ms = (tm["item_ms"] + tm["user_ms"]) / max(launches, 1)
+    bytes_item = algorithmic_bytes(nnz_loc, K, I)
+    bytes_user = algorithmic_bytes(nnz_loc, K, uc)
+    bytes_per_launch = (bytes_item * tm["item_launches"] + bytes_user * tm["user_launches"]) / max(launches, 1)
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_file):
+        try:
+            rec = json.load(open(pmc_file)).get("%s_n%d" % (args.config, world))
+            if rec:
+                traffic = rec["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": plan.describe(), "launches": launches, "avg_launch_ms": avg_ms,
+                "item_sweep_ms": tm["item_ms"] / max(tm["item_launches"], 1),
+                "user_sweep_ms": tm["user_ms"] / max(tm["user_launches"], 1),
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "note": "algorithmic bytes = nnz*(8+8K) + 16K*rows per sweep launch (SURVEY 8d); gathered rows "
+                        "that hit the 256 MiB Infinity Cache make achieved exceed real HBM traffic"}
+
+    out = {
+        "metric": "nnz_updates_per_sec", "value": total_nnz * args.steps / elapsed, "unit": "nnz-updates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s: synthetic %dx%d, K=%d, nnz=%d, alpha=%g, rows %d..%d entries, uniform columns"
+                               % (args.config, U, I, K, total_nnz, cfg["alpha"], cfg["min_row"], cfg["max_row"]),
+                   "users": U, "items": I, "K": K, "nnz": total_nnz,
+                   "parallelism": "1 GPU" if world == 1 else "row-shard x%d (by %s) + RCCL all-reduce(R) per iteration"
+                                  % (world, args.partition)},
+        "roofline": roofline, "setup_s": t_setup,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, capi)
+        out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    plan.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,149 @@
+/*
+ * matfact_hip.h -- C ABI of the MI355X (gfx950) backend for the matrix-factorisation hot path of
+ * vladstojna/recommender-system.  Plain C: pointers and sizes only, callable from the reference's C
+ * `main` (or from cgo/ctypes/JNI) with no C++ or torch types in any signature.
+ *
+ * The reference has no plugin API; the seam a maintainer would cut is the pair of calls its main makes
+ * (matFact.c:124 and :127).  Each entry point below names the reference interface it replaces.
+ *
+ *   LEVEL 1 -- host-buffer drop-ins (what the reference's main would call)
+ *     mf_backend_factorize   replaces  matrix_factorization()           matFact.c:29-59 (iteration loop)
+ *     mf_backend_recommend   replaces  mat2d_prod() + print_output()    mat2d.c:100-113, matFact.c:10-27
+ *     mf_backend_run         both, factors stay in HBM between the two  matFact.c:124-127
+ *
+ *   LEVEL 2 -- resident shard plan (one per GPU / per rank; what the MPI variant's per-rank state is)
+ *     mf_plan_*              replaces  the per-rank body of matrix_factorization()  matFact-mpi.c:155-214
+ *                            and compute_reduce_output()                            matFact-mpi.c:51-103
+ *
+ * Conventions: the caller owns every host buffer; the backend owns device memory for the duration of a
+ * level-1 call or the lifetime of a plan.  Every function returns MF_OK (0) or a negative mf_status and
+ * never calls exit() (the reference's die(), util.c:7-10, stays in the caller).  The library is HIP-only:
+ * there is no CPU fallback -- with no usable GPU every compute entry returns MF_ERR_NO_DEVICE.
+ */
+#ifndef MATFACT_HIP_H
+#define MATFACT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MATFACT_HIP_ABI_VERSION 1
+
+/* == non_zero_entry, datatypes.h:10-15: the (user, item, rating) triple, 16 bytes, array-of-structs */
+typedef struct mf_entry {
+	int32_t row;
+	int32_t col;
+	double value;
+} mf_entry;
+
+/* The parsed `.in` header plus the entries (matFact.c:79-105; dataset_info datatypes.h:17-27). */
+typedef struct mf_problem {
+	int32_t users;          /* rows of A, rows of L                 */
+	int32_t items;          /* columns of A, rows of R (R is kept transposed, matFact.c:117) */
+	int32_t features;       /* K                                    */
+	int32_t iters;
+	double alpha;
+	int64_t nnz;            /* the reference holds this in an int   */
+	const mf_entry *entries; /* file order; the reference's inputs are (row, col)-sorted and the
+	                            recommendation mask (print_output's cursor) relies on it */
+} mf_problem;
+
+typedef enum mf_status {
+	MF_OK = 0,
+	MF_ERR_ARGUMENT = -1,     /* NULL pointer, negative size, index out of range                    */
+	MF_ERR_NO_DEVICE = -2,    /* no HIP device / device index out of range                          */
+	MF_ERR_HIP = -3,          /* a HIP runtime call failed; mf_backend_last_hip_error() has its text */
+	MF_ERR_NO_MEMORY = -4,    /* host or device allocation failed                                   */
+	MF_ERR_UNSUPPORTED = -5,  /* shape outside what the kernels are built for (e.g. K too large)    */
+	MF_ERR_STATE = -6         /* plan used before factors were uploaded, etc.                       */
+} mf_status;
+
+const char *mf_backend_strerror(int status);
+const char *mf_backend_last_hip_error(void);
+int mf_backend_abi_version(void);
+int mf_backend_device_count(void);            /* >= 0, or a negative mf_status */
+
+/* ------------------------------------------------------------------------------------------ LEVEL 1 */
+
+/* L (users x K) and R (items x K), row-major fp64, are updated in place by `iters` iterations. */
+int mf_backend_factorize(const mf_problem *p, double *L, double *R, int device);
+
+/* best[i] = arg max_j (L R^T)[i][j] over the items user i has NOT rated (strict '>', ascending j, so the
+ * lowest index wins ties); -1 when user i rated every item (the reference then prints no line). */
+int mf_backend_recommend(const mf_problem *p, const double *L, const double *R, int32_t *best, int device);
+
+/* factorize + recommend with the factors resident in HBM in between; L/R receive the final factors
+ * (either may be NULL if the caller does not want them back). */
+int mf_backend_run(const mf_problem *p, double *L, double *R, int32_t *best, int device);
+
+/* ------------------------------------------------------------------------------------------ LEVEL 2 */
+
+typedef struct mf_plan mf_plan;
+
+/* One contiguous block of users (all of them for a single-GPU run) with its entries in SoA form. */
+typedef struct mf_shard {
+	int32_t users_total;
+	int32_t items;
+	int32_t features;
+	int32_t user_begin;      /* first user of this shard (BLOCK_LOW, mpiutil.h:8)        */
+	int32_t user_count;      /* users in this shard (BLOCK_SIZE, mpiutil.h:10-11)        */
+	int64_t nnz;             /* entries whose row lies in [user_begin, user_begin+count) */
+	const int32_t *row;      /* GLOBAL user ids, file order                              */
+	const int32_t *col;
+	const double *val;
+	double alpha;
+	int32_t device;          /* HIP device ordinal                                       */
+	int32_t flags;           /* MF_PLAN_* bits                                           */
+	void *items_ext[2];      /* optional caller-owned DEVICE buffers (items*features doubles each) for the
+	                            two generations of R, e.g. torch tensors handed to a collective; NULL = own */
+} mf_shard;
+
+#define MF_PLAN_DEFAULT 0
+#define MF_PLAN_RELAXED_ORDER 1   /* reserved: allow re-associated sums (tolerance mode) */
+
+int mf_plan_create(mf_plan **out, const mf_shard *shard);
+void mf_plan_destroy(mf_plan *plan);
+
+/* hipStream_t as void*; NULL = the plan's own stream.  All plan work is enqueued on it. */
+int mf_plan_set_stream(mf_plan *plan, void *hip_stream);
+
+/* host -> HBM: this shard's rows of L (user_count x K) and the whole of R (items x K). */
+int mf_plan_upload_factors(mf_plan *plan, const double *L_block, const double *R);
+int mf_plan_download_factors(mf_plan *plan, double *L_block, double *R);
+
+/* Single-shard iteration loop: per iteration one item sweep and one user sweep from the frozen
+ * generation into the next one, then flip (matFact.c:36-54; the two mat2d_copy are the ping-pong). */
+int mf_plan_iterate(mf_plan *plan, int iters);
+
+/* Sharded iteration, mirroring matFact-mpi.c:185-209 --
+ *   mf_plan_sweep_items: R_next = (seed_from_old ? R_cur : 0) + sum over LOCAL entries   (:187,:190-205)
+ *   mf_plan_sweep_users: L_next = L_cur + sum over local entries (L is private to the shard)
+ *   caller SUM-all-reduces the buffer mf_plan_items_next() over the ranks             (:208)
+ *   mf_plan_flip: next becomes current                                               */
+int mf_plan_sweep_items(mf_plan *plan, int seed_from_old);
+int mf_plan_sweep_users(mf_plan *plan);
+void *mf_plan_items_next(mf_plan *plan);     /* device pointer, items*features doubles */
+void *mf_plan_items_current(mf_plan *plan);
+int mf_plan_flip(mf_plan *plan);
+
+/* Recommendations for this shard's users against the current R; best has user_count entries. */
+int mf_plan_recommend(mf_plan *plan, int32_t *best);
+
+int mf_plan_synchronize(mf_plan *plan);
+
+/* Per-launch device timing (HIP events on the plan's stream).  After mf_plan_timing(plan, 1) every
+ * sweep launch is bracketed by events; mf_plan_timing_read drains them (synchronises) and reports
+ * launch counts and summed milliseconds of the item sweeps and of the user sweeps. */
+int mf_plan_timing(mf_plan *plan, int enable);
+int mf_plan_timing_read(mf_plan *plan, int64_t *item_launches, double *item_ms,
+                        int64_t *user_launches, double *user_ms);
+
+/* Introspection for tests/bench: name of the sweep kernel variant chosen for this K, LDS bytes, chunk. */
+int mf_plan_describe(mf_plan *plan, char *buf, int buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MATFACT_HIP_H */

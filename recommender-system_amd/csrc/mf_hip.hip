@@ -1,0 +1,608 @@
+// mf_hip.hip -- C ABI (include/matfact_hip.h) of the MI355X backend: plan management, CSR/CSC build,
+// kernel dispatch.  HIP only -- there is no CPU compute path in this library.
+#include "../../include/matfact_hip.h"
+#include "mf_kernels.hip.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_hip_error;
+
+#define MF_HIP(call)                                                                        \
+	do {                                                                                    \
+		hipError_t _e = (call);                                                             \
+		if (_e != hipSuccess) {                                                             \
+			g_last_hip_error = std::string(#call) + ": " + hipGetErrorString(_e);           \
+			return _e == hipErrorOutOfMemory ? MF_ERR_NO_MEMORY : MF_ERR_HIP;               \
+		}                                                                                   \
+	} while (0)
+
+using SweepFn = void (*)(mf::SweepArgs);
+
+struct SweepVariant {
+	SweepFn fn;
+	int kt;         // compile-time K, 0 = runtime K
+	int kpmax;      // 64-column groups held in registers (register-staged form)
+	int dma;        // 1: LDS-DMA form
+	int row_bytes;  // LDS tile row stride in bytes (DMA form)
+	int xs_bytes;   // LDS bytes in front of the tile (DMA form)
+};
+
+template <int KT, int KP>
+constexpr SweepVariant variant()
+{
+	return SweepVariant{mf::sweep_kernel<KT, KP>, KT, KP, 0, 0, 0};
+}
+
+template <int KT>
+constexpr SweepVariant dma_variant()
+{
+	return SweepVariant{mf::sweep_dma_kernel<KT>, KT, 0, 1, mf::DmaGeom<KT>::kStride, mf::DmaGeom<KT>::kXsBytes};
+}
+
+// K-specialised instances for the K of the bundled samples and of the BASELINE configs, then generic ones.
+const SweepVariant kSpecialised[] = {
+    variant<10, 1>(), variant<20, 1>(), variant<30, 1>(), variant<50, 1>(),
+    variant<100, 2>(), variant<128, 2>(), variant<256, 4>(),
+};
+// LDS-DMA form: the production kernel for these (even) K
+const SweepVariant kDma[] = {
+    dma_variant<10>(), dma_variant<20>(), dma_variant<30>(), dma_variant<50>(),
+    dma_variant<100>(), dma_variant<128>(), dma_variant<256>(),
+};
+const SweepVariant kGeneric[] = {
+    variant<0, 1>(), variant<0, 2>(), variant<0, 4>(), variant<0, 8>(),
+    variant<0, 16>(), variant<0, 32>(), variant<0, 64>(),
+};
+
+constexpr size_t kLdsPerCu = 160 * 1024;
+
+struct TimedLaunch {
+	hipEvent_t t0, t1;
+	int kind;   // 0 item sweep, 1 user sweep
+};
+
+}  // namespace
+
+struct mf_plan {
+	int device = 0;
+	int users_total = 0, items = 0, K = 0;
+	int u0 = 0, uc = 0;
+	int64_t nnz = 0;
+	double alpha = 0.0;
+	int flags = 0;
+
+	hipStream_t own_stream = nullptr;
+	hipStream_t stream = nullptr;
+
+	// CSR over the shard's users (idx = item id) and CSC over items (idx = LOCAL user id)
+	int *csr_ptr = nullptr, *csr_idx = nullptr;
+	double *csr_val = nullptr;
+	int *csc_ptr = nullptr, *csc_idx = nullptr;
+	double *csc_val = nullptr;
+
+	double *Lbuf[2] = {nullptr, nullptr};
+	double *Rbuf[2] = {nullptr, nullptr};
+	bool r_external = false;
+	int cur = 0;            // generation index of the current factors
+	bool have_factors = false;
+	int *best_dev = nullptr;
+
+	SweepVariant sweep{};
+	int nch = 0, stride = 0;
+	size_t lds_bytes = 0;
+
+	bool timing = false;
+	std::vector<TimedLaunch> timed;
+	int64_t acc_launch[2] = {0, 0};
+	double acc_ms[2] = {0.0, 0.0};
+};
+
+namespace {
+
+int choose_sweep(mf_plan *p)
+{
+	const int K = p->K;
+	p->sweep = SweepVariant{nullptr, 0, 0, 0, 0, 0};
+	const char *impl = getenv("MF_SWEEP_IMPL");   // "dma" (default) | "reg": register-staged form only
+	const bool allow_dma = !(impl && strcmp(impl, "reg") == 0);
+	if (allow_dma)
+		for (const auto &v : kDma)
+			if (v.kt == K) p->sweep = v;
+	if (!p->sweep.fn)
+		for (const auto &v : kSpecialised)
+			if (v.kt == K) p->sweep = v;
+	if (!p->sweep.fn)
+		for (const auto &v : kGeneric)
+			if (K <= v.kpmax * mf::kWave) {
+				p->sweep = v;
+				break;
+			}
+	if (!p->sweep.fn) return MF_ERR_UNSUPPORTED;
+
+	p->stride = K | 1;
+	const size_t row_bytes = p->sweep.dma ? (size_t) p->sweep.row_bytes : (size_t) p->stride * sizeof(double);
+	const size_t head = p->sweep.dma ? (size_t) p->sweep.xs_bytes : 0;
+	auto fit = [&](size_t budget) {
+		return budget > head ? (int) std::min<size_t>(64, (budget - head) / row_bytes) : 0;
+	};
+	// prefer three resident workgroups per CU, then two, then one
+	int nch = fit(kLdsPerCu / 3);
+	if (nch < 32) nch = std::max(nch, fit(kLdsPerCu / 2));
+	if (nch < 16) nch = std::max(nch, fit(kLdsPerCu));
+	if (const char *env = getenv("MF_SWEEP_NCH")) {
+		const int v = atoi(env);
+		if (v >= 1 && v <= 64 && head + (size_t) v * row_bytes <= kLdsPerCu) nch = v;
+	}
+	if (nch < 1) return MF_ERR_UNSUPPORTED;
+	p->nch = nch;
+	p->lds_bytes = head + (size_t) nch * row_bytes;
+	MF_HIP(hipFuncSetAttribute((const void *) p->sweep.fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+	                           (int) p->lds_bytes));
+	return MF_OK;
+}
+
+template <typename T>
+int dev_alloc(T **out, size_t count)
+{
+	*out = nullptr;
+	MF_HIP(hipMalloc((void **) out, std::max<size_t>(count, 1) * sizeof(T)));
+	return MF_OK;
+}
+
+// stable counting sort of the entries by `key` into (ptr, idx, val)
+void bucket(int64_t nnz, int nkeys, const int32_t *key, int32_t key_off, const int32_t *other,
+            int32_t other_off, const double *val, std::vector<int> &ptr, std::vector<int> &idx,
+            std::vector<double> &v)
+{
+	ptr.assign((size_t) nkeys + 1, 0);
+	for (int64_t n = 0; n < nnz; ++n) ptr[(size_t) (key[n] - key_off) + 1]++;
+	for (int k = 0; k < nkeys; ++k) ptr[(size_t) k + 1] += ptr[k];
+	std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+	idx.resize((size_t) nnz);
+	v.resize((size_t) nnz);
+	for (int64_t n = 0; n < nnz; ++n) {
+		const int pos = fill[(size_t) (key[n] - key_off)]++;
+		idx[(size_t) pos] = other[n] - other_off;
+		v[(size_t) pos] = val[n];
+	}
+}
+
+int launch_sweep(mf_plan *p, int kind, int seed)
+{
+	mf::SweepArgs a;
+	a.K = p->K;
+	a.nch = p->nch;
+	a.stride = p->stride;
+	a.seed = seed;
+	a.c2 = p->alpha * 2;
+	const int nxt = p->cur ^ 1;
+	if (kind == 0) {   // item sweep: X = R, Y = L, CSC
+		a.nrows = p->items;
+		a.ptr = p->csc_ptr;
+		a.idx = p->csc_idx;
+		a.val = p->csc_val;
+		a.X_old = p->Rbuf[p->cur];
+		a.Y_old = p->Lbuf[p->cur];
+		a.X_new = p->Rbuf[nxt];
+	} else {           // user sweep: X = L, Y = R, CSR
+		a.nrows = p->uc;
+		a.ptr = p->csr_ptr;
+		a.idx = p->csr_idx;
+		a.val = p->csr_val;
+		a.X_old = p->Lbuf[p->cur];
+		a.Y_old = p->Rbuf[p->cur];
+		a.X_new = p->Lbuf[nxt];
+	}
+	if (a.nrows <= 0) return MF_OK;
+	const int grid = std::min(a.nrows, 1 << 20);
+	TimedLaunch t{};
+	if (p->timing) {
+		MF_HIP(hipEventCreate(&t.t0));
+		MF_HIP(hipEventCreate(&t.t1));
+		t.kind = kind;
+		MF_HIP(hipEventRecord(t.t0, p->stream));
+	}
+	void *args[] = {&a};
+	MF_HIP(hipLaunchKernel((const void *) p->sweep.fn, dim3(grid), dim3(mf::kWave), args, p->lds_bytes,
+	                       p->stream));
+	if (p->timing) {
+		MF_HIP(hipEventRecord(t.t1, p->stream));
+		p->timed.push_back(t);
+	}
+	return MF_OK;
+}
+
+int drain_timing(mf_plan *p)
+{
+	for (auto &t : p->timed) {
+		MF_HIP(hipEventSynchronize(t.t1));
+		float ms = 0.f;
+		MF_HIP(hipEventElapsedTime(&ms, t.t0, t.t1));
+		p->acc_launch[t.kind]++;
+		p->acc_ms[t.kind] += ms;
+		(void) hipEventDestroy(t.t0);
+		(void) hipEventDestroy(t.t1);
+	}
+	p->timed.clear();
+	return MF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mf_backend_strerror(int status)
+{
+	switch (status) {
+	case MF_OK: return "ok";
+	case MF_ERR_ARGUMENT: return "invalid argument";
+	case MF_ERR_NO_DEVICE: return "no usable HIP device";
+	case MF_ERR_HIP: return "HIP runtime error";
+	case MF_ERR_NO_MEMORY: return "out of memory";
+	case MF_ERR_UNSUPPORTED: return "unsupported shape";
+	case MF_ERR_STATE: return "plan is not in a state that allows this call";
+	default: return "unknown status";
+	}
+}
+
+const char *mf_backend_last_hip_error(void) { return g_last_hip_error.c_str(); }
+
+int mf_backend_abi_version(void) { return MATFACT_HIP_ABI_VERSION; }
+
+int mf_backend_device_count(void)
+{
+	int n = 0;
+	const hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess) {
+		g_last_hip_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+		return e == hipErrorNoDevice ? 0 : MF_ERR_NO_DEVICE;
+	}
+	return n;
+}
+
+int mf_plan_create(mf_plan **out, const mf_shard *s)
+{
+	if (!out) return MF_ERR_ARGUMENT;
+	*out = nullptr;
+	if (!s || s->users_total < 0 || s->items < 0 || s->features < 1 || s->nnz < 0 || s->user_begin < 0 ||
+	    s->user_count < 0 || (int64_t) s->user_begin + s->user_count > s->users_total ||
+	    s->nnz > INT32_MAX - 64 || (s->nnz > 0 && (!s->row || !s->col || !s->val)))
+		return MF_ERR_ARGUMENT;
+	for (int64_t n = 0; n < s->nnz; ++n)
+		if (s->row[n] < s->user_begin || s->row[n] >= s->user_begin + s->user_count || s->col[n] < 0 ||
+		    s->col[n] >= s->items)
+			return MF_ERR_ARGUMENT;
+
+	const int ndev = mf_backend_device_count();
+	if (ndev <= 0 || s->device < 0 || s->device >= ndev) return MF_ERR_NO_DEVICE;
+	MF_HIP(hipSetDevice(s->device));
+
+	mf_plan *p = new (std::nothrow) mf_plan();
+	if (!p) return MF_ERR_NO_MEMORY;
+	p->device = s->device;
+	p->users_total = s->users_total;
+	p->items = s->items;
+	p->K = s->features;
+	p->u0 = s->user_begin;
+	p->uc = s->user_count;
+	p->nnz = s->nnz;
+	p->alpha = s->alpha;
+	p->flags = s->flags;
+
+	int rc = choose_sweep(p);
+	auto fail = [&](int code) {
+		mf_plan_destroy(p);
+		return code;
+	};
+	if (rc != MF_OK) return fail(rc);
+
+	if (hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(MF_ERR_HIP);
+	p->stream = p->own_stream;
+
+	std::vector<int> ptr, idx;
+	std::vector<double> val;
+	try {
+		bucket(s->nnz, p->uc, s->row, p->u0, s->col, 0, s->val, ptr, idx, val);
+	} catch (const std::bad_alloc &) {
+		return fail(MF_ERR_NO_MEMORY);
+	}
+#define MF_TRY(x)                       \
+	do {                                \
+		int _rc = (x);                  \
+		if (_rc != MF_OK) return fail(_rc); \
+	} while (0)
+#define MF_TRY_HIP(call)                                                              \
+	do {                                                                              \
+		hipError_t _e = (call);                                                       \
+		if (_e != hipSuccess) {                                                       \
+			g_last_hip_error = std::string(#call) + ": " + hipGetErrorString(_e);     \
+			return fail(_e == hipErrorOutOfMemory ? MF_ERR_NO_MEMORY : MF_ERR_HIP);   \
+		}                                                                             \
+	} while (0)
+	const size_t nz = (size_t) s->nnz;
+	MF_TRY(dev_alloc(&p->csr_ptr, (size_t) p->uc + 1));
+	MF_TRY(dev_alloc(&p->csr_idx, nz + 64));
+	MF_TRY(dev_alloc(&p->csr_val, nz + 64));
+	MF_TRY_HIP(hipMemcpy(p->csr_ptr, ptr.data(), ((size_t) p->uc + 1) * sizeof(int), hipMemcpyHostToDevice));
+	if (nz) {
+		MF_TRY_HIP(hipMemcpy(p->csr_idx, idx.data(), nz * sizeof(int), hipMemcpyHostToDevice));
+		MF_TRY_HIP(hipMemcpy(p->csr_val, val.data(), nz * sizeof(double), hipMemcpyHostToDevice));
+	}
+	try {
+		bucket(s->nnz, p->items, s->col, 0, s->row, p->u0, s->val, ptr, idx, val);
+	} catch (const std::bad_alloc &) {
+		return fail(MF_ERR_NO_MEMORY);
+	}
+	MF_TRY(dev_alloc(&p->csc_ptr, (size_t) p->items + 1));
+	MF_TRY(dev_alloc(&p->csc_idx, nz + 64));
+	MF_TRY(dev_alloc(&p->csc_val, nz + 64));
+	MF_TRY_HIP(hipMemcpy(p->csc_ptr, ptr.data(), ((size_t) p->items + 1) * sizeof(int), hipMemcpyHostToDevice));
+	if (nz) {
+		MF_TRY_HIP(hipMemcpy(p->csc_idx, idx.data(), nz * sizeof(int), hipMemcpyHostToDevice));
+		MF_TRY_HIP(hipMemcpy(p->csc_val, val.data(), nz * sizeof(double), hipMemcpyHostToDevice));
+	}
+
+	const size_t nl = (size_t) p->uc * p->K, nr = (size_t) p->items * p->K;
+	MF_TRY(dev_alloc(&p->Lbuf[0], nl));
+	MF_TRY(dev_alloc(&p->Lbuf[1], nl));
+	if (s->items_ext[0] && s->items_ext[1]) {
+		p->r_external = true;
+		p->Rbuf[0] = (double *) s->items_ext[0];
+		p->Rbuf[1] = (double *) s->items_ext[1];
+	} else {
+		MF_TRY(dev_alloc(&p->Rbuf[0], nr));
+		MF_TRY(dev_alloc(&p->Rbuf[1], nr));
+	}
+	MF_TRY(dev_alloc(&p->best_dev, (size_t) p->uc));
+#undef MF_TRY
+#undef MF_TRY_HIP
+	*out = p;
+	return MF_OK;
+}
+
+void mf_plan_destroy(mf_plan *p)
+{
+	if (!p) return;
+	(void) hipSetDevice(p->device);
+	if (p->stream) (void) hipStreamSynchronize(p->stream);
+	for (auto &t : p->timed) {
+		(void) hipEventDestroy(t.t0);
+		(void) hipEventDestroy(t.t1);
+	}
+	(void) hipFree(p->csr_ptr);
+	(void) hipFree(p->csr_idx);
+	(void) hipFree(p->csr_val);
+	(void) hipFree(p->csc_ptr);
+	(void) hipFree(p->csc_idx);
+	(void) hipFree(p->csc_val);
+	(void) hipFree(p->Lbuf[0]);
+	(void) hipFree(p->Lbuf[1]);
+	if (!p->r_external) {
+		(void) hipFree(p->Rbuf[0]);
+		(void) hipFree(p->Rbuf[1]);
+	}
+	(void) hipFree(p->best_dev);
+	if (p->own_stream) (void) hipStreamDestroy(p->own_stream);
+	delete p;
+}
+
+int mf_plan_set_stream(mf_plan *p, void *hip_stream)
+{
+	if (!p) return MF_ERR_ARGUMENT;
+	MF_HIP(hipSetDevice(p->device));
+	MF_HIP(hipStreamSynchronize(p->stream));
+	p->stream = hip_stream ? (hipStream_t) hip_stream : p->own_stream;
+	return MF_OK;
+}
+
+int mf_plan_upload_factors(mf_plan *p, const double *L_block, const double *R)
+{
+	if (!p || (!L_block && p->uc > 0) || (!R && p->items > 0)) return MF_ERR_ARGUMENT;
+	MF_HIP(hipSetDevice(p->device));
+	const size_t nl = (size_t) p->uc * p->K * sizeof(double), nr = (size_t) p->items * p->K * sizeof(double);
+	if (nl) MF_HIP(hipMemcpyAsync(p->Lbuf[p->cur], L_block, nl, hipMemcpyHostToDevice, p->stream));
+	if (nr) MF_HIP(hipMemcpyAsync(p->Rbuf[p->cur], R, nr, hipMemcpyHostToDevice, p->stream));
+	MF_HIP(hipStreamSynchronize(p->stream));
+	p->have_factors = true;
+	return MF_OK;
+}
+
+int mf_plan_download_factors(mf_plan *p, double *L_block, double *R)
+{
+	if (!p) return MF_ERR_ARGUMENT;
+	if (!p->have_factors) return MF_ERR_STATE;
+	MF_HIP(hipSetDevice(p->device));
+	const size_t nl = (size_t) p->uc * p->K * sizeof(double), nr = (size_t) p->items * p->K * sizeof(double);
+	if (L_block && nl) MF_HIP(hipMemcpyAsync(L_block, p->Lbuf[p->cur], nl, hipMemcpyDeviceToHost, p->stream));
+	if (R && nr) MF_HIP(hipMemcpyAsync(R, p->Rbuf[p->cur], nr, hipMemcpyDeviceToHost, p->stream));
+	MF_HIP(hipStreamSynchronize(p->stream));
+	return MF_OK;
+}
+
+int mf_plan_sweep_items(mf_plan *p, int seed_from_old)
+{
+	if (!p) return MF_ERR_ARGUMENT;
+	if (!p->have_factors) return MF_ERR_STATE;
+	MF_HIP(hipSetDevice(p->device));
+	return launch_sweep(p, 0, seed_from_old ? 1 : 0);
+}
+
+int mf_plan_sweep_users(mf_plan *p)
+{
+	if (!p) return MF_ERR_ARGUMENT;
+	if (!p->have_factors) return MF_ERR_STATE;
+	MF_HIP(hipSetDevice(p->device));
+	return launch_sweep(p, 1, 1);
+}
+
+void *mf_plan_items_next(mf_plan *p) { return p ? p->Rbuf[p->cur ^ 1] : nullptr; }
+void *mf_plan_items_current(mf_plan *p) { return p ? p->Rbuf[p->cur] : nullptr; }
+
+int mf_plan_flip(mf_plan *p)
+{
+	if (!p) return MF_ERR_ARGUMENT;
+	p->cur ^= 1;
+	return MF_OK;
+}
+
+int mf_plan_iterate(mf_plan *p, int iters)
+{
+	if (!p || iters < 0) return MF_ERR_ARGUMENT;
+	if (!p->have_factors) return MF_ERR_STATE;
+	MF_HIP(hipSetDevice(p->device));
+	for (int it = 0; it < iters; ++it) {
+		int rc = launch_sweep(p, 0, 1);
+		if (rc != MF_OK) return rc;
+		rc = launch_sweep(p, 1, 1);
+		if (rc != MF_OK) return rc;
+		p->cur ^= 1;
+	}
+	return MF_OK;
+}
+
+int mf_plan_recommend(mf_plan *p, int32_t *best)
+{
+	if (!p || (!best && p->uc > 0)) return MF_ERR_ARGUMENT;
+	if (!p->have_factors) return MF_ERR_STATE;
+	MF_HIP(hipSetDevice(p->device));
+	if (p->uc == 0) return MF_OK;
+	mf::RecArgs a;
+	a.users = p->uc;
+	a.items = p->items;
+	a.K = p->K;
+	a.L = p->Lbuf[p->cur];
+	a.R = p->Rbuf[p->cur];
+	a.csr_ptr = p->csr_ptr;
+	a.csr_idx = p->csr_idx;
+	a.best = p->best_dev;
+	const int grid = (p->uc + mf::kRT - 1) / mf::kRT;
+	hipLaunchKernelGGL(mf::recommend_kernel, dim3(grid), dim3(256), 0, p->stream, a);
+	MF_HIP(hipGetLastError());
+	MF_HIP(hipMemcpyAsync(best, p->best_dev, (size_t) p->uc * sizeof(int), hipMemcpyDeviceToHost, p->stream));
+	MF_HIP(hipStreamSynchronize(p->stream));
+	return MF_OK;
+}
+
+int mf_plan_synchronize(mf_plan *p)
+{
+	if (!p) return MF_ERR_ARGUMENT;
+	MF_HIP(hipSetDevice(p->device));
+	MF_HIP(hipStreamSynchronize(p->stream));
+	return MF_OK;
+}
+
+int mf_plan_timing(mf_plan *p, int enable)
+{
+	if (!p) return MF_ERR_ARGUMENT;
+	p->timing = enable != 0;
+	return MF_OK;
+}
+
+int mf_plan_timing_read(mf_plan *p, int64_t *item_launches, double *item_ms, int64_t *user_launches,
+                        double *user_ms)
+{
+	if (!p) return MF_ERR_ARGUMENT;
+	MF_HIP(hipSetDevice(p->device));
+	const int rc = drain_timing(p);
+	if (rc != MF_OK) return rc;
+	if (item_launches) *item_launches = p->acc_launch[0];
+	if (item_ms) *item_ms = p->acc_ms[0];
+	if (user_launches) *user_launches = p->acc_launch[1];
+	if (user_ms) *user_ms = p->acc_ms[1];
+	p->acc_launch[0] = p->acc_launch[1] = 0;
+	p->acc_ms[0] = p->acc_ms[1] = 0.0;
+	return MF_OK;
+}
+
+int mf_plan_describe(mf_plan *p, char *buf, int buflen)
+{
+	if (!p || !buf || buflen <= 0) return MF_ERR_ARGUMENT;
+	if (p->sweep.dma)
+		snprintf(buf, (size_t) buflen, "sweep_dma_kernel<KT=%d> K=%d nch=%d row_bytes=%d lds=%zu", p->sweep.kt,
+		         p->K, p->nch, p->sweep.row_bytes, p->lds_bytes);
+	else
+		snprintf(buf, (size_t) buflen, "sweep_kernel<KT=%d,KPMAX=%d> K=%d nch=%d stride=%d lds=%zu",
+		         p->sweep.kt, p->sweep.kpmax, p->K, p->nch, p->stride, p->lds_bytes);
+	return MF_OK;
+}
+
+/* ---------------------------------------------------------------------------------------- LEVEL 1 */
+
+static int make_single_plan(const mf_problem *pr, int device, mf_plan **out, std::vector<int32_t> &row,
+                            std::vector<int32_t> &col, std::vector<double> &val)
+{
+	if (!pr || pr->users < 0 || pr->items < 0 || pr->features < 1 || pr->nnz < 0 || pr->iters < 0 ||
+	    (pr->nnz > 0 && !pr->entries))
+		return MF_ERR_ARGUMENT;
+	try {
+		row.resize((size_t) pr->nnz);
+		col.resize((size_t) pr->nnz);
+		val.resize((size_t) pr->nnz);
+	} catch (const std::bad_alloc &) {
+		return MF_ERR_NO_MEMORY;
+	}
+	for (int64_t n = 0; n < pr->nnz; ++n) {
+		row[(size_t) n] = pr->entries[n].row;
+		col[(size_t) n] = pr->entries[n].col;
+		val[(size_t) n] = pr->entries[n].value;
+	}
+	mf_shard s;
+	memset(&s, 0, sizeof s);
+	s.users_total = pr->users;
+	s.items = pr->items;
+	s.features = pr->features;
+	s.user_begin = 0;
+	s.user_count = pr->users;
+	s.nnz = pr->nnz;
+	s.row = row.data();
+	s.col = col.data();
+	s.val = val.data();
+	s.alpha = pr->alpha;
+	s.device = device;
+	return mf_plan_create(out, &s);
+}
+
+int mf_backend_run(const mf_problem *pr, double *L, double *R, int32_t *best, int device)
+{
+	if (!pr || !L || !R) return MF_ERR_ARGUMENT;   // L and R carry the initial factors in
+	mf_plan *p = nullptr;
+	std::vector<int32_t> row, col;
+	std::vector<double> val;
+	int rc = make_single_plan(pr, device, &p, row, col, val);
+	if (rc != MF_OK) return rc;
+	rc = mf_plan_upload_factors(p, L, R);
+	if (rc == MF_OK) rc = mf_plan_iterate(p, pr->iters);
+	if (rc == MF_OK && best) rc = mf_plan_recommend(p, best);
+	if (rc == MF_OK) rc = mf_plan_download_factors(p, L, R);
+	mf_plan_destroy(p);
+	return rc;
+}
+
+int mf_backend_factorize(const mf_problem *pr, double *L, double *R, int device)
+{
+	return mf_backend_run(pr, L, R, nullptr, device);
+}
+
+int mf_backend_recommend(const mf_problem *pr, const double *L, const double *R, int32_t *best, int device)
+{
+	if (!pr || !L || !R || (!best && pr->users > 0)) return MF_ERR_ARGUMENT;
+	mf_plan *p = nullptr;
+	std::vector<int32_t> row, col;
+	std::vector<double> val;
+	int rc = make_single_plan(pr, device, &p, row, col, val);
+	if (rc != MF_OK) return rc;
+	rc = mf_plan_upload_factors(p, L, R);
+	if (rc == MF_OK) rc = mf_plan_recommend(p, best);
+	mf_plan_destroy(p);
+	return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,427 @@
+// mf_kernels.hip.h -- gfx950 (CDNA4, wave64) kernels of the matrix-factorisation hot path.
+//
+// Both kernels are "owner computes": one wavefront owns one row of the factor it updates, so no atomics
+// are needed and every floating-point sum is formed in exactly the order the serial reference forms it
+// (matFact.c:41-53): the factor matrices come out BIT-IDENTICAL to matFact.c, not merely close.
+// Build with -ffp-contract=off: the reference multiplies and adds separately (no FMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mf {
+
+constexpr int kWave = 64;
+
+// ------------------------------------------------------------------------------------------------
+// Sweep kernel.  One launch updates ONE factor from the frozen generation of both:
+//   user sweep:  X = L (rows = users of the shard),  Y = R,  (ptr, idx, val) = CSR of the shard
+//   item sweep:  X = R (rows = items),               Y = L,  (ptr, idx, val) = CSC of the shard
+// For the owned row r and each of its entries n (file order == ascending idx for sorted inputs):
+//   dot_n = sum_k X_old[r][k] * Y_old[idx_n][k]      sequential k, from 0.0       (mat2d.c:126-139)
+//   e_n   = (alpha*2) * (val_n - dot_n)                                            (matFact.c:45)
+//   X_new[r][k] = (...((seed + e_0*Y[idx_0][k]) + e_1*Y[idx_1][k]) + ...)          (matFact.c:47-51)
+// where seed = X_old[r][k], or 0 for the non-root contribution of a sharded item sweep
+// (matFact-mpi.c:187).  Mapping onto the wave, per chunk of <= nch entries of the row:
+//   stage   the nch gathered Y rows are copied, coalesced (16 B per lane), into an LDS tile whose row
+//           stride is odd in doubles, so both access patterns below are bank-conflict-free;
+//   phase A lane n walks row n of the tile and forms dot_n sequentially in k (the serial order) with
+//           X_old[r][k] as a scalar (SGPR) operand -> e_n;
+//   phase B lane l owns k = l, l+64, ...; loops n ascending, acc[k] += e_n * tile[n][k] with e_n
+//           broadcast by v_readlane -> the serial accumulation order into X[r][k].
+// Algorithmic HBM bytes per entry and sweep: 8K (the gathered row) + 12 (idx, val).
+// ------------------------------------------------------------------------------------------------
+struct SweepArgs {
+	int nrows;
+	int K;
+	int nch;      // entries per chunk (<= 64)
+	int stride;   // LDS row stride in doubles (odd)
+	int seed;     // 1: accumulate onto X_old, 0: onto zero
+	double c2;    // alpha * 2
+	const int *__restrict__ ptr;
+	const int *__restrict__ idx;
+	const double *__restrict__ val;
+	const double *__restrict__ X_old;
+	const double *__restrict__ Y_old;
+	double *__restrict__ X_new;
+};
+
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+	const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+	return __hiloint2double(hi, lo);
+}
+
+template <int KT, int KPMAX>
+__global__ void __launch_bounds__(kWave) sweep_kernel(SweepArgs a)
+{
+	extern __shared__ double tile[];
+	const int K = KT > 0 ? KT : a.K;
+	const int stride = KT > 0 ? (KT | 1) : a.stride;
+	const int nch = a.nch;
+	const int lane = threadIdx.x;
+
+	for (int r = blockIdx.x; r < a.nrows; r += gridDim.x) {
+		const int beg = a.ptr[r], end = a.ptr[r + 1];
+		const double *__restrict__ xrow = a.X_old + (size_t) r * K;
+
+		double acc[KPMAX];
+#pragma unroll
+		for (int kk = 0; kk < KPMAX; ++kk) {
+			const int k = lane + kWave * kk;
+			acc[kk] = (a.seed && k < K) ? xrow[k] : 0.0;
+		}
+
+		for (int c = beg; c < end; c += nch) {
+			const int cnt = min(nch, end - c);
+			int my_idx = 0;
+			double my_val = 0.0;
+			if (lane < cnt) {
+				my_idx = a.idx[c + lane];
+				my_val = a.val[c + lane];
+			}
+			// ---- stage: gathered rows -> LDS tile (row n of the tile = Y_old[idx_n][:])
+			for (int n = 0; n < cnt; ++n) {
+				const int j = __builtin_amdgcn_readlane(my_idx, n);
+				const double *__restrict__ yrow = a.Y_old + (size_t) j * K;
+				double *trow = tile + n * stride;
+				if ((K & 1) == 0) {
+#pragma unroll 2
+					for (int q = lane; q < (K >> 1); q += kWave) {
+						const double2 v = *reinterpret_cast<const double2 *>(yrow + 2 * q);
+						trow[2 * q] = v.x;
+						trow[2 * q + 1] = v.y;
+					}
+				} else {
+					for (int q = lane; q < K; q += kWave)
+						trow[q] = yrow[q];
+				}
+			}
+			__syncthreads();
+			// ---- phase A: lane n -> e_n (all lanes run it; lanes >= cnt produce unused garbage)
+			double e;
+			{
+				const double *t = tile + lane * stride;
+				double dot = 0.0;
+#pragma unroll 8
+				for (int k = 0; k < K; ++k)
+					dot = dot + xrow[k] * t[k];
+				e = a.c2 * (my_val - dot);
+			}
+			// ---- phase B: lane l -> columns l, l+64, ...; entries in order
+			for (int n = 0; n < cnt; ++n) {
+				const double en = readlane_f64(e, n);
+				const double *t = tile + n * stride;
+#pragma unroll
+				for (int kk = 0; kk < KPMAX; ++kk) {
+					const int k = lane + kWave * kk;
+					if (k < K)
+						acc[kk] = acc[kk] + en * t[k];
+				}
+			}
+			__syncthreads();
+		}
+#pragma unroll
+		for (int kk = 0; kk < KPMAX; ++kk) {
+			const int k = lane + kWave * kk;
+			if (k < K)
+				a.X_new[(size_t) r * K + k] = acc[kk];
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sweep kernel, LDS-DMA form (the production kernel for even, compile-time K).
+// Same arithmetic, same order, as sweep_kernel above; what changes is how the bytes move:
+//   stage   one `global_load_lds_dwordx4` per gathered row (K/2 lanes x 16 B, per-lane source address,
+//           wave-uniform LDS row base): the whole chunk -- up to 64 rows, 51 KB at K=100 -- is in flight
+//           at once with no VGPR staging and no ds_write; one vmcnt(0) retires it.
+//   tile    row stride = 16 B x (odd), so phase A's ds_read_b128 (lane n -> row n, 16-lane groups) is
+//           bank-conflict-free while every row stays 16-B aligned for the DMA.
+//   phase A lane n: 16 B of its row + 16 B of x (LDS broadcast) per step, two sequential mul/add pairs.
+//   phase B lane l owns columns 2l, 2l+1 (+128 per pass): one ds_read_b128 per entry and pass, entries
+//           in order, e_n broadcast through v_readlane into a scalar operand.
+// LDS: [ x row: XS bytes ][ tile: nch rows x S bytes ].
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void mf_gvoid;
+typedef __attribute__((address_space(3))) void mf_lvoid;
+
+template <int KT>
+struct DmaGeom {
+	static_assert(KT % 2 == 0 && KT >= 2, "LDS-DMA sweep needs an even K");
+	static constexpr int kPieces = KT / 2;                        // 16-B pieces per row
+	static constexpr int kPasses = (kPieces + kWave - 1) / kWave; // DMA instructions per row
+	static constexpr int kStride = 16 * (kPieces | 1);            // bytes, odd multiple of 16
+	static constexpr int kXsBytes = ((KT * 8 + 255) / 256) * 256;
+};
+
+template <int KT>
+__global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
+{
+	using G = DmaGeom<KT>;
+	constexpr int K = KT, P = G::kPieces, NP = G::kPasses, S = G::kStride;
+	extern __shared__ __attribute__((aligned(16))) char lds[];
+	double2 *xs = reinterpret_cast<double2 *>(lds);
+	char *tile = lds + G::kXsBytes;
+	const int nch = a.nch;
+	const int lane = threadIdx.x;
+	const unsigned voff = (unsigned) lane * 16u;
+	const unsigned long long ybase = (unsigned long long) a.Y_old;
+
+	for (int r = blockIdx.x; r < a.nrows; r += gridDim.x) {
+		const int beg = a.ptr[r], end = a.ptr[r + 1];
+		const double2 *__restrict__ xrow2 = reinterpret_cast<const double2 *>(a.X_old + (size_t) r * K);
+
+		double2 acc[NP];
+#pragma unroll
+		for (int p = 0; p < NP; ++p) {
+			const int q = lane + kWave * p;
+			double2 v = make_double2(0.0, 0.0);
+			if (q < P) {
+				v = xrow2[q];
+				xs[q] = v;
+			}
+			acc[p] = a.seed ? v : make_double2(0.0, 0.0);
+		}
+
+		for (int c = beg; c < end; c += nch) {
+			const int cnt = min(nch, end - c);
+			int my_idx = 0;
+			double my_val = 0.0;
+			if (lane < cnt) {
+				my_idx = a.idx[c + lane];
+				my_val = a.val[c + lane];
+			}
+			// ---- stage: one DMA per gathered row and pass
+			for (int n = 0; n < cnt; ++n) {
+				const int j = __builtin_amdgcn_readlane(my_idx, n);
+				unsigned long long base = ybase + (unsigned long long) (unsigned) j * (unsigned long long) (K * 8);
+				asm volatile("" : "+s"(base));   // keep the row base scalar
+#pragma unroll
+				for (int p = 0; p < NP; ++p) {
+					const char *src = reinterpret_cast<const char *>(base) + voff + 1024u * p;
+					if (lane + kWave * p < P)
+						__builtin_amdgcn_global_load_lds((mf_gvoid *) src, (mf_lvoid *) (tile + n * S + 1024 * p),
+						                                 16, 0, 0);
+				}
+			}
+			__syncthreads();   // single-wave workgroup: this is the vmcnt(0)/lgkmcnt(0) that retires the DMA
+			// ---- phase A
+			double e;
+			{
+				const double2 *t2 = reinterpret_cast<const double2 *>(tile + lane * S);
+				double dot = 0.0;
+#pragma unroll
+				for (int q = 0; q < P; ++q) {
+					const double2 t = t2[q];
+					const double2 x = xs[q];
+					dot = dot + x.x * t.x;
+					dot = dot + x.y * t.y;
+				}
+				e = a.c2 * (my_val - dot);
+			}
+			// ---- phase B
+			const char *tb = tile + voff;
+			int n = 0;
+			for (; n + 4 <= cnt; n += 4) {
+				double2 t[4][NP];
+				double en[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					en[u] = readlane_f64(e, n + u);
+#pragma unroll
+					for (int p = 0; p < NP; ++p)
+						t[u][p] = (lane + kWave * p < P)
+						              ? *reinterpret_cast<const double2 *>(tb + (n + u) * S + 1024 * p)
+						              : make_double2(0.0, 0.0);
+				}
+#pragma unroll
+				for (int u = 0; u < 4; ++u)
+#pragma unroll
+					for (int p = 0; p < NP; ++p) {
+						acc[p].x = acc[p].x + en[u] * t[u][p].x;
+						acc[p].y = acc[p].y + en[u] * t[u][p].y;
+					}
+			}
+			for (; n < cnt; ++n) {
+				const double en = readlane_f64(e, n);
+#pragma unroll
+				for (int p = 0; p < NP; ++p)
+					if (lane + kWave * p < P) {
+						const double2 t = *reinterpret_cast<const double2 *>(tb + n * S + 1024 * p);
+						acc[p].x = acc[p].x + en * t.x;
+						acc[p].y = acc[p].y + en * t.y;
+					}
+			}
+			__syncthreads();   // tile is overwritten by the next chunk's DMA
+		}
+		double2 *__restrict__ out2 = reinterpret_cast<double2 *>(a.X_new + (size_t) r * K);
+#pragma unroll
+		for (int p = 0; p < NP; ++p) {
+			const int q = lane + kWave * p;
+			if (q < P) out2[q] = acc[p];
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Recommend kernel (exact form): fused L_blk * R^T with a masked running arg-max; B is never stored.
+// One 256-thread workgroup owns 64 users and walks all item tiles (64 items) in ascending order.
+// Each thread accumulates a 4x4 register block sequentially in k from 0.0 (mat2d.c:100-113 order), so
+// every score equals the reference's B[i][j] bit for bit.  Rated (i, j) are excluded by a per-user
+// cursor over the shard's CSR row (print_output's `aix`, matFact.c:13-23); ties keep the lower j.
+// ------------------------------------------------------------------------------------------------
+struct RecArgs {
+	int users;    // users in this shard
+	int items;
+	int K;
+	const double *__restrict__ L;    // users x K
+	const double *__restrict__ R;    // items x K
+	const int *__restrict__ csr_ptr; // users + 1
+	const int *__restrict__ csr_idx; // item ids, ascending within a user
+	int *__restrict__ best;          // users
+};
+
+struct Cand {
+	double bv;   // best non-NaN value so far
+	int bi;      // its index, -1 if none
+	int first;   // first unrated index, -1 if none
+	int fnan;    // that first unrated score is NaN
+};
+
+__device__ __forceinline__ void cand_insert(Cand &c, double s, int j)
+{
+	const bool nan = s != s;
+	if (c.first < 0) {
+		c.first = j;
+		c.fnan = nan;
+	}
+	if (!nan && (c.bi < 0 || s > c.bv)) {
+		c.bv = s;
+		c.bi = j;
+	}
+}
+
+// left = earlier items, right = later items
+__device__ __forceinline__ void cand_merge(Cand &l, const Cand &r)
+{
+	if (l.first < 0) {
+		l.first = r.first;
+		l.fnan = r.fnan;
+	}
+	if (r.bi >= 0 && (l.bi < 0 || r.bv > l.bv)) {
+		l.bv = r.bv;
+		l.bi = r.bi;
+	}
+}
+
+constexpr int kRT = 64;   // users per workgroup, items per tile
+constexpr int kRKC = 16;  // k chunk staged in LDS
+constexpr int kRLD = kRT + 2;
+
+__global__ void __launch_bounds__(256) recommend_kernel(RecArgs a)
+{
+	__shared__ double Ls[kRKC][kRLD];
+	__shared__ double Rs[kRKC][kRLD];
+	__shared__ unsigned long long maskw[kRT];
+
+	const int tid = threadIdx.x;
+	const int tx = tid & 15, ty = tid >> 4;
+	const int i0 = blockIdx.x * kRT;
+	const int K = a.K;
+
+	// cursor state of the mask walker (threads 0..63: one user each)
+	int cur = 0, cend = 0, nextcol = INT32_MAX;
+	if (tid < kRT && i0 + tid < a.users) {
+		cur = a.csr_ptr[i0 + tid];
+		cend = a.csr_ptr[i0 + tid + 1];
+		nextcol = cur < cend ? a.csr_idx[cur] : INT32_MAX;
+	}
+	// running result, kept by the tx == 0 lane of each 16-lane group for its 4 users
+	Cand run[4];
+#pragma unroll
+	for (int u = 0; u < 4; ++u) run[u] = Cand{0.0, -1, -1, 0};
+
+	// staging roles: thread -> (row = tid / 4, 4 consecutive k starting at (tid % 4) * 4)
+	const int srow = tid >> 2, sk = (tid & 3) * 4;
+
+	for (int j0 = 0; j0 < a.items; j0 += kRT) {
+		double acc[4][4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u)
+#pragma unroll
+			for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+
+		for (int kc = 0; kc < K; kc += kRKC) {
+			{
+				const int ui = i0 + srow, ij = j0 + srow;
+#pragma unroll
+				for (int x = 0; x < 4; ++x) {
+					const int k = kc + sk + x;
+					Ls[sk + x][srow] = (ui < a.users && k < K) ? a.L[(size_t) ui * K + k] : 0.0;
+					Rs[sk + x][srow] = (ij < a.items && k < K) ? a.R[(size_t) ij * K + k] : 0.0;
+				}
+			}
+			__syncthreads();
+			const int kmax = min(kRKC, K - kc);
+			for (int k = 0; k < kmax; ++k) {
+				double l[4], r[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) l[u] = Ls[k][ty * 4 + u];
+#pragma unroll
+				for (int v = 0; v < 4; ++v) r[v] = Rs[k][tx * 4 + v];
+#pragma unroll
+				for (int u = 0; u < 4; ++u)
+#pragma unroll
+					for (int v = 0; v < 4; ++v) acc[u][v] = acc[u][v] + l[u] * r[v];
+			}
+			__syncthreads();
+		}
+
+		// rated-item mask of this tile, one 64-bit word per user
+		if (tid < kRT) {
+			unsigned long long m = 0;
+			while (nextcol < j0 + kRT) {
+				if (nextcol >= j0) m |= 1ull << (nextcol - j0);
+				++cur;
+				nextcol = cur < cend ? a.csr_idx[cur] : INT32_MAX;
+			}
+			maskw[tid] = m;
+		}
+		__syncthreads();
+
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const unsigned long long m = maskw[ty * 4 + u];
+			Cand c{0.0, -1, -1, 0};
+#pragma unroll
+			for (int v = 0; v < 4; ++v) {
+				const int jj = tx * 4 + v;
+				if (j0 + jj < a.items && !((m >> jj) & 1ull)) cand_insert(c, acc[u][v], j0 + jj);
+			}
+			// ordered merge over the 16 lanes that hold this user's 64 items (ascending tx)
+#pragma unroll
+			for (int d = 1; d < 16; d <<= 1) {
+				Cand o;
+				o.bv = __shfl_down(c.bv, d, 16);
+				o.bi = __shfl_down(c.bi, d, 16);
+				o.first = __shfl_down(c.first, d, 16);
+				o.fnan = __shfl_down(c.fnan, d, 16);
+				if (tx + d < 16) cand_merge(c, o);
+			}
+			if (tx == 0) cand_merge(run[u], c);
+		}
+		__syncthreads();   // maskw is rewritten by the next tile
+	}
+
+	if (tx == 0) {
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const int i = i0 + ty * 4 + u;
+			if (i < a.users)
+				a.best[i] = run[u].first < 0 ? -1 : (run[u].fnan ? run[u].first : run[u].bi);
+		}
+	}
+}
+
+}  // namespace mf

@@ -1,0 +1,303 @@
+/*
+ * mf_host.c -- host-side helpers of the MI355X matFact build (see include/matfact_host.h).
+ * Pure C, no GPU dependency.  Each function cites the reference code whose behaviour it keeps.
+ */
+#define _GNU_SOURCE
+#include "../../include/matfact_host.h"
+
+#include <errno.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ parsing */
+
+const char *mf_host_parse_strerror(int status)
+{
+	switch (status) {
+	case MF_PARSE_OK: return "ok";
+	case MF_PARSE_OPEN: return "Unable to open input file.";           /* matFact.c:76 */
+	case MF_PARSE_INT: return "Error in int argument.";                /* util.c:14 */
+	case MF_PARSE_DOUBLE: return "Error in double argument.";          /* util.c:20 */
+	case MF_PARSE_THREE_INTS: return "Error in multiple int argument."; /* util.c:26 */
+	case MF_PARSE_ENTRY: return "Error in non-zero entry.";            /* util.c:32 */
+	case MF_PARSE_CLOSE: return "Unable to close input file.";         /* matFact.c:109 */
+	case MF_PARSE_NOMEM: return "Out of memory.";
+	default: return "Unknown parse error.";
+	}
+}
+
+/* the tokens fscanf("%d") / fscanf("%lf") would take: skip white space, then the longest valid prefix */
+static int take_int(const char **cur, const char *end, int *out)
+{
+	const char *p = *cur;
+	while (p < end && (*p == ' ' || (*p >= '\t' && *p <= '\r'))) ++p;
+	if (p >= end) return 0;
+	int neg = 0;
+	if (*p == '+' || *p == '-') neg = (*p++ == '-');
+	if (p >= end || *p < '0' || *p > '9') return 0;
+	long long v = 0;
+	while (p < end && *p >= '0' && *p <= '9') {
+		v = v * 10 + (*p++ - '0');
+		if (v > 0x7fffffffLL + 1) v = 0x7fffffffLL + 1;   /* saturate; the reference overflows (UB) */
+	}
+	*out = (int) (neg ? -v : v);
+	*cur = p;
+	return 1;
+}
+
+static int take_double(const char **cur, const char *end, double *out)
+{
+	const char *p = *cur;
+	while (p < end && (*p == ' ' || (*p >= '\t' && *p <= '\r'))) ++p;
+	if (p >= end) return 0;
+	char *stop = NULL;
+	const double v = strtod(p, &stop);   /* the buffer is NUL-terminated by the callers */
+	if (stop == p) return 0;
+	*out = v;
+	*cur = stop;
+	return 1;
+}
+
+int mf_host_parse_buffer(const char *text, size_t len, mf_problem *p)
+{
+	memset(p, 0, sizeof *p);
+	const char *cur = text, *end = text + len;
+	int iters, feats, users, items, nnz;
+	double alpha;
+	if (!take_int(&cur, end, &iters)) return MF_PARSE_INT;
+	if (!take_double(&cur, end, &alpha)) return MF_PARSE_DOUBLE;
+	if (!take_int(&cur, end, &feats)) return MF_PARSE_INT;
+	if (!take_int(&cur, end, &users) || !take_int(&cur, end, &items) || !take_int(&cur, end, &nnz))
+		return MF_PARSE_THREE_INTS;
+	mf_entry *e = malloc(sizeof(mf_entry) * (size_t) (nnz > 0 ? nnz : 1));
+	if (!e) return MF_PARSE_NOMEM;
+	for (int n = 0; n < nnz; n++) {
+		int r, c;
+		double v;
+		if (!take_int(&cur, end, &r) || !take_int(&cur, end, &c) || !take_double(&cur, end, &v)) {
+			free(e);
+			return MF_PARSE_ENTRY;
+		}
+		e[n].row = r;
+		e[n].col = c;
+		e[n].value = v;
+	}
+	p->iters = iters;
+	p->alpha = alpha;
+	p->features = feats;
+	p->users = users;
+	p->items = items;
+	p->nnz = nnz > 0 ? nnz : 0;
+	p->entries = e;
+	return MF_PARSE_OK;
+}
+
+int mf_host_parse_file(const char *path, mf_problem *p)
+{
+	memset(p, 0, sizeof *p);
+	FILE *fp = fopen(path, "r");
+	if (!fp) return MF_PARSE_OPEN;
+	size_t cap = 1 << 16, len = 0;
+	char *buf = malloc(cap + 1);
+	if (!buf) {
+		fclose(fp);
+		return MF_PARSE_NOMEM;
+	}
+	for (;;) {
+		const size_t got = fread(buf + len, 1, cap - len, fp);
+		len += got;
+		if (got == 0) break;
+		if (len == cap) {
+			cap *= 2;
+			char *nb = realloc(buf, cap + 1);
+			if (!nb) {
+				free(buf);
+				fclose(fp);
+				return MF_PARSE_NOMEM;
+			}
+			buf = nb;
+		}
+	}
+	buf[len] = '\0';
+	if (fclose(fp) == EOF) {
+		free(buf);
+		return MF_PARSE_CLOSE;
+	}
+	const int rc = mf_host_parse_buffer(buf, len, p);
+	free(buf);
+	return rc;
+}
+
+void mf_host_free_problem(mf_problem *p)
+{
+	if (p) {
+		free((void *) p->entries);
+		p->entries = NULL;
+		p->nnz = 0;
+	}
+}
+
+/* ------------------------------------------------------------------------- glibc TYPE_3 random() */
+
+/* srandom(): r[0] = seed (0 -> 1); r[i] = 16807 * r[i-1] mod (2^31 - 1) by Schrage's split; front cursor
+ * 3 ahead of the back cursor; the first 310 outputs are discarded.  random(): ring[f] += ring[b];
+ * result = that word >> 1.  (srandom(0) in mat2d.c:62 therefore behaves as seed 1.) */
+void mf_host_srandom(mf_rand *g, unsigned seed)
+{
+	if (seed == 0) seed = 1;
+	int32_t word = (int32_t) seed;
+	g->ring[0] = word;
+	for (int i = 1; i < 31; i++) {
+		const long hi = word / 127773, lo = word % 127773;
+		long w = 16807 * lo - 2836 * hi;
+		if (w < 0) w += 2147483647;
+		word = (int32_t) w;
+		g->ring[i] = word;
+	}
+	g->f = 3;
+	g->b = 0;
+	for (int i = 0; i < 310; i++) (void) mf_host_random(g);
+}
+
+int32_t mf_host_random(mf_rand *g)
+{
+	const uint32_t v = (uint32_t) g->ring[g->f] + (uint32_t) g->ring[g->b];
+	g->ring[g->f] = (int32_t) v;
+	if (++g->f >= 31) g->f = 0;
+	if (++g->b >= 31) g->b = 0;
+	return (int32_t) (v >> 1);
+}
+
+#define MF_RAND_MAX 2147483647
+
+void mf_host_init_factors_block(int users, int items, int features, int u0, int count, double *L_block,
+                                double *R)
+{
+	mf_rand g;
+	mf_host_srandom(&g, 0);
+	const double norm = (double) features;
+	/* L[u][k] in row-major draw order (mat2d.c:65-67); rows outside the block are drawn and dropped */
+	for (int64_t u = 0; u < users; u++) {
+		if (u >= u0 && u < (int64_t) u0 + count) {
+			double *dst = L_block + (u - u0) * features;
+			for (int k = 0; k < features; k++)
+				dst[k] = ((double) mf_host_random(&g) / (double) MF_RAND_MAX) / norm;
+		} else {
+			for (int k = 0; k < features; k++) (void) mf_host_random(&g);
+		}
+	}
+	/* R_init[k][j] in row-major draw order (mat2d.c:69-71), stored transposed (mat2d.c:115-124) */
+	if (R)
+		for (int k = 0; k < features; k++)
+			for (int64_t j = 0; j < items; j++)
+				R[j * features + k] = ((double) mf_host_random(&g) / (double) MF_RAND_MAX) / norm;
+}
+
+void mf_host_init_factors(int users, int items, int features, double *L, double *R)
+{
+	mf_host_init_factors_block(users, items, features, 0, users, L, R);
+}
+
+void mf_host_split_entries(const mf_entry *e, int64_t nnz, int32_t *row, int32_t *col, double *val)
+{
+	for (int64_t n = 0; n < nnz; n++) {
+		row[n] = e[n].row;
+		col[n] = e[n].col;
+		val[n] = e[n].value;
+	}
+}
+
+/* ---------------------------------------------------------------------------------- partitioning */
+
+int mf_host_partition_users(int users, int parts, int by_entries, const int64_t *row_ptr, int32_t *begin)
+{
+	if (users < 0 || parts < 1 || !begin || (by_entries && !row_ptr)) return -1;
+	if (!by_entries) {
+		for (int p = 0; p <= parts; p++) begin[p] = (int32_t) mf_host_block_low(p, parts, users);
+		return 0;
+	}
+	const int64_t total = row_ptr[users];
+	begin[0] = 0;
+	int u = 0;
+	for (int p = 1; p < parts; p++) {
+		const int64_t target = total * p / parts;
+		/* first row boundary at or after the target, never behind the previous cut */
+		while (u < users && row_ptr[u] < target) u++;
+		begin[p] = u;
+	}
+	begin[parts] = users;
+	return 0;
+}
+
+int mf_host_write_out(FILE *f, const int32_t *best, int users)
+{
+	for (int i = 0; i < users; i++)
+		if (best[i] >= 0 && fprintf(f, "%d\n", best[i]) < 0) return -1;
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------- synthetic */
+
+static inline uint64_t splitmix64(uint64_t *x)
+{
+	uint64_t z = (*x += 0x9E3779B97F4A7C15ull);
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+
+static inline uint64_t row_state(const mf_synth *s, int u)
+{
+	uint64_t x = s->seed ^ (0xD1B54A32D192ED03ull * (uint64_t) (u + 1));
+	(void) splitmix64(&x);
+	return x;
+}
+
+static inline int32_t row_count(const mf_synth *s, int u)
+{
+	uint64_t x = row_state(s, u);
+	const uint64_t span = (uint64_t) (s->max_row - s->min_row + 1);
+	int64_t m = s->min_row + (int64_t) (splitmix64(&x) % span);
+	if (m > s->items) m = s->items;
+	if (m < 0) m = 0;
+	return (int32_t) m;
+}
+
+int64_t mf_host_synth_counts(const mf_synth *s, int u0, int count, int32_t *counts)
+{
+	int64_t total = 0;
+	#pragma omp parallel for schedule(static) reduction(+ : total)
+	for (int i = 0; i < count; i++) {
+		counts[i] = row_count(s, u0 + i);
+		total += counts[i];
+	}
+	return total;
+}
+
+/* Row u: m strata of [0, items), one uniformly drawn column in each -> m distinct ascending columns with a
+ * uniform column marginal; rating uniform in {1,...,5}. */
+int mf_host_synth_fill(const mf_synth *s, int u0, int count, const int32_t *counts, int32_t *row,
+                       int32_t *col, double *val)
+{
+	int64_t *off = malloc(sizeof(int64_t) * ((size_t) count + 1));
+	if (!off) return -1;
+	off[0] = 0;
+	for (int i = 0; i < count; i++) off[i + 1] = off[i] + counts[i];
+	#pragma omp parallel for schedule(dynamic, 1024)
+	for (int i = 0; i < count; i++) {
+		const int u = u0 + i;
+		uint64_t x = row_state(s, u);
+		(void) splitmix64(&x);   /* the draw that fixed the count */
+		const int64_t m = counts[i];
+		int64_t o = off[i];
+		for (int64_t t = 0; t < m; t++, o++) {
+			const int64_t lo = t * s->items / m, hi = (t + 1) * s->items / m;
+			const uint64_t z = splitmix64(&x);
+			row[o] = u;
+			col[o] = (int32_t) (lo + (int64_t) ((z >> 8) % (uint64_t) (hi - lo)));
+			val[o] = (double) (1 + (int) (z & 0xff) % 5);
+		}
+	}
+	free(off);
+	return 0;
+}

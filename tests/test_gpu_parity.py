@@ -1,0 +1,241 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against the CPU
+oracle on the same seeded inputs, against the committed golden fixtures (the reference's own outputs), and --
+at sizes the oracle cannot finish -- through exact spot checks and size-independent properties.
+
+Bar: factor matrices BIT-EXACT (the kernels keep the serial summation order; north-star tolerance is 1e-5
+relative, we hold 0), recommendations bit-identical."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_in, random_instance, to_text
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(capi):
+    if capi.device_count() < 1:
+        pytest.fail("GPU tests need an MI355X; mf_backend_device_count() = %d" % capi.device_count())
+
+
+def _inst(capi, d):
+    return capi.Instance(d["iters"], d["alpha"], d["feats"], d["users"], d["items"], d["row"], d["col"], d["val"])
+
+
+def _oracle_run(orc, d, iters=None):
+    inst = orc.Instance(**d)
+    L, R = orc.init_factors(inst.users, inst.items, inst.feats)
+    orc.factorize(inst, L, R, iters=iters)
+    return L, R, orc.recommend(inst, L, R)
+
+
+# ------------------------------------------------------------------ golden fixtures (reference's own outputs)
+@pytest.mark.parametrize("name", ["inst0", "inst1", "inst2", "inst30-40-10-2-10", "inst1000-1000-100-2-30",
+                                  "instML100k"])
+def test_golden_full_run(capi, name):
+    inst = capi.parse_file(golden_in(name))
+    L, R = capi.init_factors(inst.users, inst.items, inst.feats)
+    best = capi.backend_run(inst, L, R)
+    snap = np.load(os.path.join(GOLDEN, name + ".factors.npz"))
+    assert np.array_equal(L, snap["L_full"]), "L differs from the reference's factors"
+    assert np.array_equal(R, snap["R_full"]), "R differs from the reference's factors"
+    out = "".join("%d\n" % b for b in best if b >= 0)
+    assert out == open(os.path.join(GOLDEN, name + ".out")).read()
+
+
+@pytest.mark.parametrize("name", ["inst0", "inst2", "inst30-40-10-2-10"])
+def test_golden_snapshots(capi, name):
+    inst = capi.parse_file(golden_in(name))
+    snap = np.load(os.path.join(GOLDEN, name + ".factors.npz"))
+    for it in (1, 2, 10):
+        L, R = capi.init_factors(inst.users, inst.items, inst.feats)
+        capi.backend_factorize(inst, L, R, iters=it)
+        assert np.array_equal(L, snap["L_%d" % it]) and np.array_equal(R, snap["R_%d" % it]), it
+
+
+@pytest.mark.parametrize("name", ["inst0", "inst30-40-10-2-10", "instML100k"])
+def test_cli_stdout_is_byte_identical_to_out(capi, name, tmp_path):
+    path = golden_in(name)
+    if path.endswith(".gz"):
+        import gzip
+        raw = gzip.open(path, "rb").read()
+        path = str(tmp_path / (name + ".in"))
+        open(path, "wb").write(raw)
+    r = subprocess.run([capi.CLI_PATH, path], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == open(os.path.join(GOLDEN, name + ".out"), "rb").read()
+
+
+# ------------------------------------------------------------------ seeded random instances vs the oracle
+SHAPES = [
+    # users, items, K
+    (1, 1, 1), (5, 7, 2), (17, 9, 3), (40, 33, 7), (30, 40, 10), (64, 64, 20), (90, 70, 30), (33, 65, 31),
+    (70, 50, 50), (50, 80, 64), (45, 45, 65), (120, 90, 100), (60, 70, 128), (40, 40, 130), (80, 60, 256),
+    (24, 20, 300), (12, 10, 1000),
+]
+
+
+@pytest.mark.parametrize("impl", ["dma", "reg"])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_random_instance_bit_exact(capi, orc, shape, impl, monkeypatch):
+    monkeypatch.setenv("MF_SWEEP_IMPL", impl)
+    u, i, k = shape
+    d = random_instance(1000 + u + 7 * i + 13 * k, u, i, k, density=0.35, iters=4, alpha=0.002,
+                        empty_rows=(0,) if u > 3 else (), full_rows=(2,) if u > 3 else (), float_ratings=True)
+    L, R = capi.init_factors(u, i, k)
+    best = capi.backend_run(_inst(capi, d), L, R)
+    Lo, Ro, bo = _oracle_run(orc, d)
+    assert np.array_equal(L, Lo) and np.array_equal(R, Ro)
+    assert np.array_equal(best, bo)
+
+
+def test_long_rows_cross_chunks(capi, orc):
+    """Rows and columns with several 64-entry chunks, and a chunk size forced small."""
+    d = random_instance(77, 300, 260, 100, density=0.9, iters=2, alpha=1e-4)
+    L, R = capi.init_factors(300, 260, 100)
+    best = capi.backend_run(_inst(capi, d), L, R)
+    Lo, Ro, bo = _oracle_run(orc, d)
+    assert np.array_equal(L, Lo) and np.array_equal(R, Ro) and np.array_equal(best, bo)
+    for nch in ("1", "7", "33"):
+        os.environ["MF_SWEEP_NCH"] = nch
+        try:
+            L2, R2 = capi.init_factors(300, 260, 100)
+            capi.backend_factorize(_inst(capi, d), L2, R2)
+        finally:
+            del os.environ["MF_SWEEP_NCH"]
+        assert np.array_equal(L2, Lo) and np.array_equal(R2, Ro), nch
+
+
+def test_empty_and_degenerate_inputs(capi, orc):
+    # no entries at all: factors unchanged, every user gets the arg-max over all items
+    d = dict(iters=3, alpha=0.01, feats=4, users=6, items=5, row=np.zeros(0, np.int32), col=np.zeros(0, np.int32),
+             val=np.zeros(0))
+    L, R = capi.init_factors(6, 5, 4)
+    L0, R0 = L.copy(), R.copy()
+    best = capi.backend_run(_inst(capi, d), L, R)
+    assert np.array_equal(L, L0) and np.array_equal(R, R0)
+    assert np.array_equal(best, _oracle_run(orc, d)[2])
+    # zero iterations: only the recommendation step
+    d = random_instance(3, 20, 30, 5, iters=0)
+    L, R = capi.init_factors(20, 30, 5)
+    best = capi.backend_run(_inst(capi, d), L, R)
+    assert np.array_equal(best, _oracle_run(orc, d)[2])
+    # unsorted entries: the factorisation follows FILE order (stable bucketing), as the serial loop does
+    d = random_instance(4, 25, 20, 6, iters=3, density=0.4)
+    perm = np.random.default_rng(0).permutation(len(d["row"]))
+    for key in ("row", "col", "val"):
+        d[key] = np.ascontiguousarray(d[key][perm])
+    L, R = capi.init_factors(25, 20, 6)
+    capi.backend_factorize(_inst(capi, d), L, R)
+    Lo, Ro = orc.init_factors(25, 20, 6)
+    orc.factorize(orc.Instance(**d), Lo, Ro)
+    assert np.array_equal(L, Lo) and np.array_equal(R, Ro)
+
+
+def test_argument_errors(capi):
+    d = random_instance(1, 5, 5, 3)
+    d["col"][0] = 99
+    L, R = capi.init_factors(5, 5, 3)
+    with pytest.raises(capi.HipBackendError) as e:
+        capi.backend_run(_inst(capi, d), L, R)
+    assert e.value.status == capi.MF_ERR_ARGUMENT
+    d = random_instance(1, 5, 5, 3)
+    with pytest.raises(capi.HipBackendError) as e:
+        capi.Plan(5, 5, 3, 0.1, d["row"], d["col"], d["val"], device=99)
+    assert e.value.status == capi.MF_ERR_NO_DEVICE
+
+
+def test_recommend_ties_masks_and_nan(capi, orc):
+    u, i, k = 70, 150, 8
+    rng = np.random.default_rng(5)
+    L = rng.standard_normal((u, k))
+    R = rng.standard_normal((i, k))
+    R[40] = R[10]          # exact ties: the lower index must win
+    R[149] = R[10]
+    R[64] = R[3]
+    d = random_instance(8, u, i, k, density=0.3, full_rows=(5, 66), empty_rows=(6,))
+    L[9, :] = np.nan       # all scores NaN: the first unrated item is kept (strict '>' never fires)
+    R[0, 0] = np.inf
+    inst = _inst(capi, d)
+    best = capi.backend_recommend(inst, L, R)
+    assert np.array_equal(best, orc.recommend(orc.Instance(**d), L, R))
+    assert best[5] == -1 and best[66] == -1
+
+
+def test_plan_sharded_sweeps_match_oracle_shard_step(capi, orc):
+    """matFact-mpi.c:187-208 semantics of the level-2 API: per-shard aux buffers, root seeds from old."""
+    d = random_instance(31, 90, 60, 20, density=0.3, iters=1, alpha=0.003)
+    L, R = capi.init_factors(90, 60, 20)
+    cuts = [0, 25, 61, 90]
+    R_sum = np.zeros_like(R)
+    for g in range(3):
+        sel = (d["row"] >= cuts[g]) & (d["row"] < cuts[g + 1])
+        plan = capi.Plan(90, 60, 20, d["alpha"], d["row"][sel], d["col"][sel], d["val"][sel], user_begin=cuts[g],
+                         user_count=cuts[g + 1] - cuts[g])
+        Lb = np.ascontiguousarray(L[cuts[g]:cuts[g + 1]])
+        plan.upload(Lb, R)
+        plan.sweep_items(seed_from_old=(g == 0))
+        plan.sweep_users()
+        plan.flip()
+        Ln, Ra = plan.download()
+        Lo, Rao = orc.shard_step(cuts[g], cuts[g + 1] - cuts[g], 60, 20, d["row"][sel], d["col"][sel], d["val"][sel],
+                                 d["alpha"], Lb, R, g == 0)
+        assert np.array_equal(Ln, Lo) and np.array_equal(Ra, Rao)
+        R_sum += Ra
+        plan.close()
+    Ls, Rs = L.copy(), R.copy()
+    orc.factorize(orc.Instance(**d), Ls, Rs, iters=1)
+    assert np.allclose(R_sum, Rs, rtol=1e-12, atol=1e-15)
+
+
+# ------------------------------------------------------------------ full-size: exact spot checks + properties
+def test_large_synthetic_spot_checks_and_properties(capi, orc):
+    """2e5 x 2e4, K=100, ~2e7 entries (cfg4's shape at 1/5 scale; the serial oracle would need minutes per
+    iteration).  Exact checks on sampled rows: a row of L_new depends only on that user's entries and R_old,
+    a row of R_new only on that item's entries and L_old -- so the oracle, fed the filtered entries in file
+    order, reproduces those rows bit for bit."""
+    U, I, K, alpha = 200_000, 20_000, 100, 1e-4
+    row, col, val = capi.synth_block(0xC0FFEE + 4, U, I, 50, 150)
+    L0, R0 = capi.init_factors(U, I, K)
+    plan = capi.Plan(U, I, K, alpha, row, col, val)
+    plan.upload(L0, R0)
+    plan.iterate(1)
+    L1, R1 = plan.download()
+    rng = np.random.default_rng(0)
+    users = np.sort(rng.choice(U, 300, replace=False))
+    sel = np.isin(row, users)
+    Lo, _ = orc.shard_step(0, U, I, K, row[sel], col[sel], val[sel], alpha, L0, R0, True)
+    assert np.array_equal(L1[users], Lo[users])
+    items = np.sort(rng.choice(I, 40, replace=False))
+    sel = np.isin(col, items)
+    _, Ro = orc.shard_step(0, U, I, K, row[sel], col[sel], val[sel], alpha, L0, R0, True)
+    assert np.array_equal(R1[items], Ro[items])
+    # determinism: a second plan run is bit-identical
+    plan2 = capi.Plan(U, I, K, alpha, row, col, val)
+    plan2.upload(L0, R0)
+    plan2.iterate(1)
+    L1b, R1b = plan2.download()
+    assert np.array_equal(L1, L1b) and np.array_equal(R1, R1b)
+    # alpha = 0 is the identity (e = 0 * (a - dot) = 0 exactly)
+    plan3 = capi.Plan(U, I, K, 0.0, row, col, val)
+    plan3.upload(L0, R0)
+    plan3.iterate(2)
+    Lz, Rz = plan3.download()
+    assert np.array_equal(Lz, L0) and np.array_equal(Rz, R0)
+    plan3.close()
+    plan2.close()
+    # recommendations: exact check of sampled users against the oracle's row scorer + the mask rule
+    best = plan.recommend()
+    ptr = np.concatenate([[0], np.cumsum(np.bincount(row, minlength=U))])
+    for uu in users[:40]:
+        b = orc.predict_row(L1[uu], R1)
+        rated = set(col[ptr[uu]:ptr[uu + 1]].tolist())
+        exp = -1
+        for j in range(I):
+            if j not in rated and (exp == -1 or b[j] > b[exp]):
+                exp = j
+        assert best[uu] == exp
+    plan.close()
