@@ -46,8 +46,9 @@ def cpu_baseline(cfg, capi, budget_s=12.0):
     workload: the first `sample_users` users (all items, same K), loop time only."""
     from oracle import oracle as O
     O.build(o3=True, ref=False)
-    cores = len(os.sched_getaffinity(0))
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    # the GPU box gives one GPU a 16-core share of the host; the reference's own runs used <= 16 threads too
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     sample_users = min(cfg["users"], 100_000)
     row, col, val = capi.synth_block(cfg["seed"], cfg["users"], cfg["items"], cfg["min_row"], cfg["max_row"],
                                      0, sample_users)
@@ -57,11 +58,13 @@ def cpu_baseline(cfg, capi, budget_s=12.0):
     R = rng.random((cfg["items"], K)) / K
     nnz = int(row.shape[0])
     t0 = time.time()
-    sec, thr = O.factorize_omp(sample_users, cfg["items"], K, row, col, val, 1, cfg["alpha"], L, R, o3=True)
+    sec, thr = O.factorize_omp(sample_users, cfg["items"], K, row, col, val, 1, cfg["alpha"], L, R, o3=True,
+                               threads=cores)
     iters, total_sec, total_it = 1, sec, 1
     while time.time() - t0 < budget_s and total_it < 50:
         iters = max(1, min(10, int((budget_s - (time.time() - t0)) / max(sec, 1e-3) / 2)))
-        s, thr = O.factorize_omp(sample_users, cfg["items"], K, row, col, val, iters, cfg["alpha"], L, R, o3=True)
+        s, thr = O.factorize_omp(sample_users, cfg["items"], K, row, col, val, iters, cfg["alpha"], L, R, o3=True,
+                                 threads=cores)
         total_sec += s
         total_it += iters
         sec = s / iters

@@ -238,6 +238,16 @@ double orc_factorize_omp(int users, int items, int feats, int64_t nnz,
 	return (double) (t1.tv_sec - t0.tv_sec) + 1e-9 * (double) (t1.tv_nsec - t0.tv_nsec);
 }
 
+/* thread count of the OpenMP legs (libgomp may have read OMP_NUM_THREADS long before we are loaded) */
+void orc_set_threads(int n)
+{
+#ifdef _OPENMP
+	if (n > 0) omp_set_num_threads(n);
+#else
+	(void) n;
+#endif
+}
+
 /* serial loop with the same timing convention, for a 1-core baseline figure */
 double orc_factorize_timed(int users, int items, int feats, int64_t nnz,
                            const int32_t *row, const int32_t *col, const double *val,

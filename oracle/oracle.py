@@ -55,6 +55,8 @@ def _lib(o3=False):
         lib.orc_shard_step.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _i32p, _i32p, _f64p,
                                        C.c_double, _f64p, _f64p, C.c_int, _f64p, _f64p]
         lib.orc_shard_step.restype = None
+        lib.orc_set_threads.argtypes = [C.c_int]
+        lib.orc_set_threads.restype = None
         _libs[name] = lib
     return _libs[name]
 
@@ -143,9 +145,11 @@ def run(inst):
     return L, R, recommend(inst, L, R)
 
 
-def factorize_omp(users, items, feats, row, col, val, iters, alpha, L, R, o3=True):
+def factorize_omp(users, items, feats, row, col, val, iters, alpha, L, R, o3=True, threads=None):
     """OpenMP REDUCTION=1 port (matFact-omp.c:35-144). Sorts by column first when items > users
     (matFact-omp.c:44-48).  Returns (seconds in the iteration loop, threads used)."""
+    if threads:
+        _lib(o3).orc_set_threads(int(threads))
     if items > users:
         order = np.lexsort((row, col))
         row, col, val = (np.ascontiguousarray(a[order]) for a in (row, col, val))

@@ -133,10 +133,15 @@ int choose_sweep(mf_plan *p)
 	auto fit = [&](size_t budget) {
 		return budget > head ? (int) std::min<size_t>(64, (budget - head) / row_bytes) : 0;
 	};
-	// prefer three resident workgroups per CU, then two, then one
-	int nch = fit(kLdsPerCu / 3);
-	if (nch < 32) nch = std::max(nch, fit(kLdsPerCu / 2));
-	if (nch < 16) nch = std::max(nch, fit(kLdsPerCu));
+	// Chunk size = latency hiding vs fixed cost.  Each single-wave workgroup alternates "gather a chunk"
+	// and "compute on it", so the bytes in flight per CU come from OTHER resident workgroups: small tiles
+	// (~13 KB -> ~11 workgroups per CU) beat big ones (measured on cfg4, K=100: nch 64/32/16/8 ->
+	// 37.1/29.3/24.1/25.5 ms per iteration); phase A costs K steps per chunk whatever its size, which is
+	// what stops the trend below ~12 entries.
+	// K=256: nch 8/12/16/24 -> 71/66/78/82 ms (12 rows = 6 workgroups per CU); K=30: nch 16..32 best.
+	int nch = 16;
+	if (head + (size_t) nch * row_bytes > kLdsPerCu / 6) nch = std::max(12, fit(kLdsPerCu / 6));
+	nch = std::min(nch, fit(kLdsPerCu));
 	if (const char *env = getenv("MF_SWEEP_NCH")) {
 		const int v = atoi(env);
 		if (v >= 1 && v <= 64 && head + (size_t) v * row_bytes <= kLdsPerCu) nch = v;
