@@ -89,6 +89,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--partition", default="entries", choices=["entries", "rows"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo only to rehearse several ranks on ONE GPU")
+    ap.add_argument("--recommend", action="store_true",
+                    help="also time the fused L*R^T masked top-1 step (reported beside, never inside, `value`)")
+    ap.add_argument("--check", action="store_true",
+                    help="after the timed region compare the factors with a single-shard run on rank 0's GPU")
     args = ap.parse_args()
 
     cfg = dict(CONFIGS[args.config])
@@ -109,10 +115,17 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available() or capi.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and local_rank >= ndev:
+        raise SystemExit("rank %d has no GPU (%d visible): RCCL needs one GPU per rank" % (local_rank, ndev))
+    local_dev = local_rank % ndev
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     U, I, K = cfg["users"], cfg["items"], cfg["feats"]
     # ---- this rank's block of the synthetic instance
@@ -126,7 +139,7 @@ def main():
     nnz_loc = int(row.shape[0])
     Lb, R0 = capi.init_factors_block(U, I, K, u0, uc)     # the reference's init rule (mat2d.c:61-72)
     r_bufs = [torch.empty(I, K, dtype=torch.float64, device=dev) for _ in range(2)]
-    plan = capi.Plan(U, I, K, cfg["alpha"], row, col, val, user_begin=u0, user_count=uc, device=local_rank,
+    plan = capi.Plan(U, I, K, cfg["alpha"], row, col, val, user_begin=u0, user_count=uc, device=local_dev,
                      items_ext=[t.data_ptr() for t in r_bufs])
     del row, col, val
     stream = torch.cuda.current_stream()
@@ -200,6 +213,37 @@ def main():
         out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     elif rank == 0:
         out["cpu_baseline"] = None
+    if args.recommend:
+        fence()
+        t0 = time.perf_counter()
+        best = run.gather_recommendations(U, begin)
+        fence()
+        rs_ = time.perf_counter() - t0
+        out["recommend"] = {"seconds": rs_, "flop": 2.0 * U * I * K, "tflops": 2.0 * U * I * K / rs_ / 1e12,
+                            "peak_tflops_fp64": 78.6, "recommended": int((best >= 0).sum()),
+                            "mode": os.environ.get("MF_RECOMMEND_IMPL", "default")}
+    if args.check:
+        # whole-instance single-shard run on this GPU vs the sharded result (rank 0 only; small configs)
+        Lparts = [None] * world
+        mine = plan.download(want_r=False)[0]
+        if world > 1:
+            dist.all_gather_object(Lparts, mine)
+        else:
+            Lparts = [mine]
+        if rank == 0:
+            row, col, val = capi.synth_block(cfg["seed"], U, I, cfg["min_row"], cfg["max_row"])
+            L0, R0 = capi.init_factors(U, I, K)
+            ref = capi.Plan(U, I, K, cfg["alpha"], row, col, val, device=local_dev)
+            ref.upload(L0, R0)
+            ref.iterate(args.warmup + args.steps)
+            Lr, Rr = ref.download()
+            ref.close()
+            Rs = run.current_items().cpu().numpy()
+            Ls = np.concatenate(Lparts)
+            def rel(a, b):
+                return float(np.max(np.abs(a - b) / (np.abs(b) + 1e-300)))
+            out["check"] = {"L_max_rel": rel(Ls, Lr), "R_max_rel": rel(Rs, Rr),
+                            "L_bit_identical": bool(np.array_equal(Ls, Lr)), "R_bit_identical": bool(np.array_equal(Rs, Rr))}
     if rank == 0:
         print(json.dumps(out), flush=True)
     plan.close()

@@ -239,3 +239,27 @@ def test_large_synthetic_spot_checks_and_properties(capi, orc):
                 exp = j
         assert best[uu] == exp
     plan.close()
+
+
+def test_two_ranks_one_gpu_sharded_bench(capi):
+    """The real multi-rank path (bench.py -> sharded.py -> HIP plan with caller-owned R buffers), two ranks
+    sharing the one GPU of this box, gloo moving the CUDA tensors (RCCL refuses two ranks on one device).
+    bench.py --check compares the sharded factors with a single-shard run: L and R within 1e-9 relative
+    (only the 2-way re-association of the R sum differs; north-star tolerance 1e-5)."""
+    import json
+    import socket
+    import sys
+    from conftest import ROOT
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--config", "twin", "--backend", "gloo", "--check"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["check"]["L_max_rel"] < 1e-9 and out["check"]["R_max_rel"] < 1e-9, out["check"]
