@@ -220,7 +220,7 @@ def main():
         fence()
         rs_ = time.perf_counter() - t0
         out["recommend"] = {"seconds": rs_, "flop": 2.0 * U * I * K, "tflops": 2.0 * U * I * K / rs_ / 1e12,
-                            "peak_tflops_fp64": 78.6, "recommended": int((best >= 0).sum()),
+                            "peak_tflops_fp64": 78.6, "recommended": int((best >= 0).sum()), "exact_pass_users": plan.recommend_info(),
                             "mode": os.environ.get("MF_RECOMMEND_IMPL", "default")}
     if args.check:
         # whole-instance single-shard run on this GPU vs the sharded result (rank 0 only; small configs)

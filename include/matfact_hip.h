@@ -128,8 +128,13 @@ void *mf_plan_items_next(mf_plan *plan);     /* device pointer, items*features d
 void *mf_plan_items_current(mf_plan *plan);
 int mf_plan_flip(mf_plan *plan);
 
-/* Recommendations for this shard's users against the current R; best has user_count entries. */
+/* Recommendations for this shard's users against the current R; best has user_count entries.
+ * Default form: scores on the FP64 matrix cores (MFMA), every user whose best/second-best margin is not
+ * provably larger than the rounding bound re-scored in the reference's exact order, so the result is the
+ * reference's arg-max in all cases.  MF_RECOMMEND_IMPL=exact forces the exact form for every user. */
 int mf_plan_recommend(mf_plan *plan, int32_t *best);
+/* users the last mf_plan_recommend sent through the exact pass (-1 when the exact form ran for all) */
+int mf_plan_recommend_info(mf_plan *plan, int64_t *exact_pass_users);
 
 int mf_plan_synchronize(mf_plan *plan);
 

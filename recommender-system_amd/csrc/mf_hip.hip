@@ -94,6 +94,11 @@ struct mf_plan {
 	int cur = 0;            // generation index of the current factors
 	bool have_factors = false;
 	int *best_dev = nullptr;
+	// MFMA recommend scratch
+	double *lnorm = nullptr;
+	unsigned long long *rmax_bits = nullptr;
+	int *ulist = nullptr, *ucount = nullptr;
+	int64_t last_uncertain = -1;   // users re-scored by the exact pass in the last recommend (-1: exact form ran)
 
 	SweepVariant sweep{};
 	int nch = 0, stride = 0;
@@ -367,6 +372,10 @@ int mf_plan_create(mf_plan **out, const mf_shard *s)
 		MF_TRY(dev_alloc(&p->Rbuf[1], nr));
 	}
 	MF_TRY(dev_alloc(&p->best_dev, (size_t) p->uc));
+	MF_TRY(dev_alloc(&p->lnorm, (size_t) p->uc));
+	MF_TRY(dev_alloc(&p->rmax_bits, 1));
+	MF_TRY(dev_alloc(&p->ulist, (size_t) p->uc));
+	MF_TRY(dev_alloc(&p->ucount, 1));
 #undef MF_TRY
 #undef MF_TRY_HIP
 	*out = p;
@@ -395,6 +404,10 @@ void mf_plan_destroy(mf_plan *p)
 		(void) hipFree(p->Rbuf[1]);
 	}
 	(void) hipFree(p->best_dev);
+	(void) hipFree(p->lnorm);
+	(void) hipFree(p->rmax_bits);
+	(void) hipFree(p->ulist);
+	(void) hipFree(p->ucount);
 	if (p->own_stream) (void) hipStreamDestroy(p->own_stream);
 	delete p;
 }
@@ -479,20 +492,74 @@ int mf_plan_recommend(mf_plan *p, int32_t *best)
 	if (!p->have_factors) return MF_ERR_STATE;
 	MF_HIP(hipSetDevice(p->device));
 	if (p->uc == 0) return MF_OK;
-	mf::RecArgs a;
-	a.users = p->uc;
-	a.items = p->items;
-	a.K = p->K;
-	a.L = p->Lbuf[p->cur];
-	a.R = p->Rbuf[p->cur];
-	a.csr_ptr = p->csr_ptr;
-	a.csr_idx = p->csr_idx;
-	a.best = p->best_dev;
-	const int grid = (p->uc + mf::kRT - 1) / mf::kRT;
-	hipLaunchKernelGGL(mf::recommend_kernel, dim3(grid), dim3(256), 0, p->stream, a);
-	MF_HIP(hipGetLastError());
+	const char *impl = getenv("MF_RECOMMEND_IMPL");   // "mfma" (default) | "exact"
+	const bool use_mfma = !(impl && strcmp(impl, "exact") == 0);
+	mf::RecArgs ex;
+	ex.users = p->uc;
+	ex.items = p->items;
+	ex.K = p->K;
+	ex.L = p->Lbuf[p->cur];
+	ex.R = p->Rbuf[p->cur];
+	ex.csr_ptr = p->csr_ptr;
+	ex.csr_idx = p->csr_idx;
+	ex.best = p->best_dev;
+	ex.ulist = nullptr;
+	if (!use_mfma) {
+		const int grid = (p->uc + mf::kRT - 1) / mf::kRT;
+		hipLaunchKernelGGL(mf::recommend_kernel, dim3(grid), dim3(256), 0, p->stream, ex);
+		MF_HIP(hipGetLastError());
+		p->last_uncertain = -1;
+	} else {
+		// pass 1: scores on the FP64 matrix cores + certification margin; pass 2: exact re-scoring of the rest
+		MF_HIP(hipMemsetAsync(p->rmax_bits, 0, sizeof(unsigned long long), p->stream));
+		MF_HIP(hipMemsetAsync(p->ucount, 0, sizeof(int), p->stream));
+		hipLaunchKernelGGL(mf::row_norm_kernel, dim3((p->uc + 63) / 64), dim3(64), 0, p->stream, ex.L, p->uc,
+		                   p->K, p->lnorm, (unsigned long long *) nullptr);
+		if (p->items > 0)
+			hipLaunchKernelGGL(mf::row_norm_kernel, dim3((p->items + 63) / 64), dim3(64), 0, p->stream, ex.R,
+			                   p->items, p->K, (double *) nullptr, p->rmax_bits);
+		mf::RecMfmaArgs m;
+		m.users = p->uc;
+		m.items = p->items;
+		m.K = p->K;
+		m.L = ex.L;
+		m.R = ex.R;
+		m.csr_ptr = p->csr_ptr;
+		m.csr_idx = p->csr_idx;
+		m.lnorm = p->lnorm;
+		m.rnorm_max_bits = p->rmax_bits;
+		m.thr_scale = 8.0 * (double) (p->K + 8) * 1.1102230246251565e-16;
+		m.best = p->best_dev;
+		m.ulist = p->ulist;
+		m.ucount = p->ucount;
+		if ((p->K & 1) == 0)
+			hipLaunchKernelGGL(mf::recommend_mfma_kernel<true>, dim3((p->uc + mf::kMU - 1) / mf::kMU),
+			                   dim3(mf::kMThreads), 0, p->stream, m);
+		else
+			hipLaunchKernelGGL(mf::recommend_mfma_kernel<false>, dim3((p->uc + mf::kMU - 1) / mf::kMU),
+			                   dim3(mf::kMThreads), 0, p->stream, m);
+		MF_HIP(hipGetLastError());
+		int cnt = 0;
+		MF_HIP(hipMemcpyAsync(&cnt, p->ucount, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+		MF_HIP(hipStreamSynchronize(p->stream));
+		p->last_uncertain = cnt;
+		if (cnt > 0) {
+			ex.users = cnt;
+			ex.ulist = p->ulist;
+			hipLaunchKernelGGL(mf::recommend_kernel, dim3((cnt + mf::kRT - 1) / mf::kRT), dim3(256), 0, p->stream,
+			                   ex);
+			MF_HIP(hipGetLastError());
+		}
+	}
 	MF_HIP(hipMemcpyAsync(best, p->best_dev, (size_t) p->uc * sizeof(int), hipMemcpyDeviceToHost, p->stream));
 	MF_HIP(hipStreamSynchronize(p->stream));
+	return MF_OK;
+}
+
+int mf_plan_recommend_info(mf_plan *p, int64_t *exact_pass_users)
+{
+	if (!p || !exact_pass_users) return MF_ERR_ARGUMENT;
+	*exact_pass_users = p->last_uncertain;
 	return MF_OK;
 }
 

@@ -280,6 +280,7 @@ struct RecArgs {
 	const int *__restrict__ csr_ptr; // users + 1
 	const int *__restrict__ csr_idx; // item ids, ascending within a user
 	int *__restrict__ best;          // users
+	const int *__restrict__ ulist;   // optional: only these users (indices into the shard), `users` = its length
 };
 
 struct Cand {
@@ -333,8 +334,9 @@ __global__ void __launch_bounds__(256) recommend_kernel(RecArgs a)
 	// cursor state of the mask walker (threads 0..63: one user each)
 	int cur = 0, cend = 0, nextcol = INT32_MAX;
 	if (tid < kRT && i0 + tid < a.users) {
-		cur = a.csr_ptr[i0 + tid];
-		cend = a.csr_ptr[i0 + tid + 1];
+		const int uid = a.ulist ? a.ulist[i0 + tid] : i0 + tid;
+		cur = a.csr_ptr[uid];
+		cend = a.csr_ptr[uid + 1];
 		nextcol = cur < cend ? a.csr_idx[cur] : INT32_MAX;
 	}
 	// running result, kept by the tx == 0 lane of each 16-lane group for its 4 users
@@ -344,6 +346,7 @@ __global__ void __launch_bounds__(256) recommend_kernel(RecArgs a)
 
 	// staging roles: thread -> (row = tid / 4, 4 consecutive k starting at (tid % 4) * 4)
 	const int srow = tid >> 2, sk = (tid & 3) * 4;
+	const int suid = (i0 + srow < a.users) ? (a.ulist ? a.ulist[i0 + srow] : i0 + srow) : -1;
 
 	for (int j0 = 0; j0 < a.items; j0 += kRT) {
 		double acc[4][4];
@@ -354,11 +357,11 @@ __global__ void __launch_bounds__(256) recommend_kernel(RecArgs a)
 
 		for (int kc = 0; kc < K; kc += kRKC) {
 			{
-				const int ui = i0 + srow, ij = j0 + srow;
+				const int ij = j0 + srow;
 #pragma unroll
 				for (int x = 0; x < 4; ++x) {
 					const int k = kc + sk + x;
-					Ls[sk + x][srow] = (ui < a.users && k < K) ? a.L[(size_t) ui * K + k] : 0.0;
+					Ls[sk + x][srow] = (suid >= 0 && k < K) ? a.L[(size_t) suid * K + k] : 0.0;
 					Rs[sk + x][srow] = (ij < a.items && k < K) ? a.R[(size_t) ij * K + k] : 0.0;
 				}
 			}
@@ -419,7 +422,292 @@ __global__ void __launch_bounds__(256) recommend_kernel(RecArgs a)
 		for (int u = 0; u < 4; ++u) {
 			const int i = i0 + ty * 4 + u;
 			if (i < a.users)
-				a.best[i] = run[u].first < 0 ? -1 : (run[u].fnan ? run[u].first : run[u].bi);
+				a.best[a.ulist ? a.ulist[i] : i] =
+				    run[u].first < 0 ? -1 : (run[u].fnan ? run[u].first : run[u].bi);
+		}
+	}
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Recommend kernel, MFMA form: scores on the FP64 matrix cores, answers certified exact.
+//   pass 1 (this kernel)  S~ = L_blk * R^T with v_mfma_f64_16x16x4_f64; per user the best and the
+//          second-best score over unrated items are tracked.  For ANY summation order and fusing,
+//          |S~ - B| <= 2*gamma_K * |l|.|r| <= 2*gamma_K*||l||*||r||  (B = the reference's sequential,
+//          unfused value), so when best - second > thr_i = c*(K+8)*2^-53*||L[i]||*max_j||R[j]|| (c = 8, a
+//          4x margin) the approximate arg-max IS the reference's arg-max and no tie rule is involved.
+//   pass 2 (recommend_kernel with `ulist`)  every other user -- near-ties, exact ties (the lowest index
+//          must win), non-finite scores -- is re-scored in the reference's exact order.
+// Tile: 256 threads = 4 waves (2 x 2) own 128 users x 64 items per step; each wave holds 4 x 2
+// accumulator tiles of 16 x 16 (64 VGPRs); L and R k-chunks of 16 go through LDS stored k-major with a
+// leading dimension that puts the two 16-lane halves of a ds_read_b64 group on disjoint banks.
+// MFMA operand maps (f64 16x16x4): A lane l = A[l&15][l>>4], B lane l = B[l>>4][l&15],
+// D lane l reg r = D[(l>>4) + 4r][l&15].
+// ------------------------------------------------------------------------------------------------
+struct RecMfmaArgs {
+	int users, items, K;
+	const double *__restrict__ L;
+	const double *__restrict__ R;
+	const int *__restrict__ csr_ptr;
+	const int *__restrict__ csr_idx;
+	const double *__restrict__ lnorm;          // ||L[i]||_2 per user
+	const unsigned long long *__restrict__ rnorm_max_bits;   // max_j ||R[j]||_2 as the bits of a double
+	double thr_scale;                          // c * (K + 8) * 2^-53
+	int *__restrict__ best;
+	int *__restrict__ ulist;                   // out: users that need the exact pass
+	int *__restrict__ ucount;
+};
+
+__global__ void __launch_bounds__(kWave) row_norm_kernel(const double *__restrict__ X, int rows, int K,
+                                                          double *__restrict__ norm,
+                                                          unsigned long long *__restrict__ max_bits)
+{
+	const int r = blockIdx.x * kWave + threadIdx.x;
+	double s = 0.0;
+	if (r < rows)
+		for (int k = 0; k < K; ++k) {
+			const double v = X[(size_t) r * K + k];
+			s += v * v;
+		}
+	s = sqrt(s);
+	if (r < rows && norm) norm[r] = s;
+	if (max_bits) {
+		// NaN compares as a huge unsigned pattern: it poisons the maximum, which sends every user to pass 2
+		unsigned long long b = (r < rows) ? (unsigned long long) __double_as_longlong(s) : 0ull;
+		for (int d = 32; d >= 1; d >>= 1) {
+			const unsigned long long o = __shfl_xor(b, d);
+			b = o > b ? o : b;
+		}
+		if (threadIdx.x == 0) atomicMax(max_bits, b);
+	}
+}
+
+constexpr int kMU = 128, kMI = 128, kMKC = 32;
+constexpr int kMLD = 128 + 16;   // k-major rows of 144 doubles: lanes 16..31 of a read land 32 banks further
+constexpr int kMThreads = 512;
+
+struct Top2 {
+	double b1, b2;
+	int i1;
+};
+
+// b1 = -inf / i1 = -1 encode "no candidate"; all values are finite or -inf, so plain comparisons suffice
+__device__ __forceinline__ void top2_merge(Top2 &a, const Top2 &b)
+{
+	const bool take = b.b1 > a.b1;
+	const double lo1 = take ? a.b1 : b.b1;          // the smaller of the two bests
+	const double hi2 = take ? b.b2 : a.b2;          // the winner's own runner-up
+	a.b2 = lo1 > hi2 ? lo1 : hi2;
+	a.b1 = take ? b.b1 : a.b1;
+	a.i1 = take ? b.i1 : a.i1;
+}
+
+typedef double mf_d4 __attribute__((ext_vector_type(4)));
+
+// 512 threads = 8 waves as 4 (user quarters of 32) x 2 (item halves of 64): two waves per SIMD, so one
+// wave's staging, LDS traffic and arg-max bookkeeping run under the other's matrix instructions.
+template <bool VEC>   // VEC: K even -> rows are 16-B aligned, 16-byte global loads
+__global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a)
+{
+	__shared__ double As[kMKC][kMLD];
+	__shared__ double Bs[kMKC][kMLD];
+	__shared__ unsigned long long maskw[kMU][2];
+	__shared__ double red_b1[kMU][2], red_b2[kMU][2];
+	__shared__ int red_i1[kMU][2], red_bad[kMU][2];
+
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int wr = wave >> 1, wc = wave & 1;
+	const int lr = lane & 15, lq = lane >> 4;
+	const int i0 = blockIdx.x * kMU;
+	const int K = a.K;
+	const double ninf = -__builtin_inf();
+
+	// mask walker: threads 0..127, one user each
+	int cur = 0, cend = 0, nextcol = INT32_MAX;
+	if (tid < kMU && i0 + tid < a.users) {
+		cur = a.csr_ptr[i0 + tid];
+		cend = a.csr_ptr[i0 + tid + 1];
+		nextcol = cur < cend ? a.csr_idx[cur] : INT32_MAX;
+	}
+
+	// running top-2 of the 8 rows this lane sees: row(tu, r) = 32*wr + 16*tu + lq + 4*r
+	double b1[8], b2[8];
+	int i1[8];
+	unsigned bad = 0;
+#pragma unroll
+	for (int x = 0; x < 8; ++x) {
+		b1[x] = ninf;
+		b2[x] = ninf;
+		i1[x] = -1;
+	}
+
+	// staging roles: A and B chunks are 128 rows x 32 k, 8 consecutive doubles per thread
+	constexpr int SN = 8;
+	const int srow = tid >> 2, sk = (tid & 3) * SN;
+	const bool a_ok = i0 + srow < a.users;
+	const double *__restrict__ aptr = a.L + (size_t) (a_ok ? i0 + srow : 0) * K;
+	double av[SN], bv[SN];
+
+	// global -> registers for chunk (tile jt, k offset kc); zero outside the matrices
+	auto fetch = [&](int jt, int kc) {
+		const bool b_ok = jt + srow < a.items;
+		const double *__restrict__ bptr = a.R + (size_t) (b_ok ? jt + srow : 0) * K;
+		if (VEC) {
+#pragma unroll
+			for (int x = 0; x < SN; x += 2) {
+				const int k = kc + sk + x;
+				const double2 va = (a_ok && k < K) ? *reinterpret_cast<const double2 *>(aptr + k) : make_double2(0.0, 0.0);
+				const double2 vb = (b_ok && k < K) ? *reinterpret_cast<const double2 *>(bptr + k) : make_double2(0.0, 0.0);
+				av[x] = va.x;
+				av[x + 1] = va.y;
+				bv[x] = vb.x;
+				bv[x + 1] = vb.y;
+			}
+		} else {
+#pragma unroll
+			for (int x = 0; x < SN; ++x) {
+				const int k = kc + sk + x;
+				av[x] = (a_ok && k < K) ? aptr[k] : 0.0;
+				bv[x] = (b_ok && k < K) ? bptr[k] : 0.0;
+			}
+		}
+	};
+
+	fetch(0, 0);
+	for (int j0 = 0; j0 < a.items; j0 += kMI) {
+		mf_d4 acc[2][4];
+#pragma unroll
+		for (int tu = 0; tu < 2; ++tu)
+#pragma unroll
+			for (int ti = 0; ti < 4; ++ti) acc[tu][ti] = mf_d4{0.0, 0.0, 0.0, 0.0};
+
+		for (int kc = 0; kc < K; kc += kMKC) {
+			__syncthreads();   // previous chunk's fragment reads are done
+#pragma unroll
+			for (int x = 0; x < SN; ++x) {
+				As[sk + x][srow] = av[x];
+				Bs[sk + x][srow] = bv[x];
+			}
+			__syncthreads();
+			// prefetch the next chunk (of this tile, or the first of the next tile) behind the MFMAs
+			if (kc + kMKC < K)
+				fetch(j0, kc + kMKC);
+			else if (j0 + kMI < a.items)
+				fetch(j0 + kMI, 0);
+			auto kstep = [&](int ks) {
+				double fa[2], fb[4];
+#pragma unroll
+				for (int tu = 0; tu < 2; ++tu) fa[tu] = As[ks * 4 + lq][32 * wr + 16 * tu + lr];
+#pragma unroll
+				for (int ti = 0; ti < 4; ++ti) fb[ti] = Bs[ks * 4 + lq][64 * wc + 16 * ti + lr];
+#pragma unroll
+				for (int tu = 0; tu < 2; ++tu)
+#pragma unroll
+					for (int ti = 0; ti < 4; ++ti)
+						acc[tu][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[tu], fb[ti], acc[tu][ti], 0, 0, 0);
+			};
+			if (kc + kMKC <= K) {
+#pragma unroll
+				for (int ks = 0; ks < kMKC / 4; ++ks) kstep(ks);
+			} else {   // last chunk: skip the zero padding beyond K
+				const int ksteps = (K - kc + 3) >> 2;
+				for (int ks = 0; ks < ksteps; ++ks) kstep(ks);
+			}
+		}
+
+		// rated-item mask of this tile: bit jj of word w = item j0 + 64*w + jj is rated or beyond the last item
+		if (tid < kMU) {
+			unsigned long long m0 = 0, m1 = 0;
+			while (nextcol < j0 + kMI) {
+				const int o = nextcol - j0;
+				if (o >= 64)
+					m1 |= 1ull << (o - 64);
+				else if (o >= 0)
+					m0 |= 1ull << o;
+				++cur;
+				nextcol = cur < cend ? a.csr_idx[cur] : INT32_MAX;
+			}
+			const int left = a.items - j0;   // > 0
+			if (left < 64) {
+				m0 |= ~0ull << left;
+				m1 = ~0ull;
+			} else if (left < 128) {
+				m1 |= ~0ull << (left - 64);
+			}
+			maskw[tid][0] = m0;
+			maskw[tid][1] = m1;
+		}
+		__syncthreads();
+#pragma unroll
+		for (int tu = 0; tu < 2; ++tu)
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const int x = tu * 4 + r;
+				const unsigned long long m = maskw[32 * wr + 16 * tu + lq + 4 * r][wc] >> lr;
+				// cheap reject: after the first tiles almost no score beats the row's runner-up
+				bool any = false;
+#pragma unroll
+				for (int ti = 0; ti < 4; ++ti) {
+					const double v = acc[tu][ti][r];
+					any |= !((m >> (16 * ti)) & 1ull) && !(v <= b2[x] && v >= -1.7976931348623157e308);   // v > b2, NaN, +-inf
+				}
+				if (__builtin_amdgcn_ballot_w64(any) != 0) {
+#pragma unroll
+					for (int ti = 0; ti < 4; ++ti) {
+						// branch-free insert: b1 starts at -inf, so "first candidate" needs no special case
+						const double v = acc[tu][ti][r];
+						const int j = j0 + 64 * wc + 16 * ti + lr;
+						const bool open = !((m >> (16 * ti)) & 1ull);
+						const bool fin = fabs(v) <= 1.7976931348623157e308;
+						bad |= (unsigned) (open && !fin) << x;
+						const bool use = open && fin;
+						const bool gt1 = use && v > b1[x];
+						const bool gt2 = use && !gt1 && v > b2[x];
+						b2[x] = gt1 ? b1[x] : (gt2 ? v : b2[x]);
+						b1[x] = gt1 ? v : b1[x];
+						i1[x] = gt1 ? j : i1[x];
+					}
+				}
+			}
+		__syncthreads();   // maskw is rewritten by the next tile
+	}
+
+	// merge the 16 lanes (lr) that share a row, then the two item halves (wc), then decide
+#pragma unroll
+	for (int x = 0; x < 8; ++x) {
+		Top2 t{b1[x], b2[x], i1[x]};
+		int bd = (bad >> x) & 1;
+#pragma unroll
+		for (int d = 1; d < 16; d <<= 1) {
+			Top2 o;
+			o.b1 = __shfl_xor(t.b1, d, 16);
+			o.b2 = __shfl_xor(t.b2, d, 16);
+			o.i1 = __shfl_xor(t.i1, d, 16);
+			bd |= __shfl_xor(bd, d, 16);
+			top2_merge(t, o);
+		}
+		if (lr == 0) {
+			const int row = 32 * wr + 16 * (x >> 2) + lq + 4 * (x & 3);
+			red_b1[row][wc] = t.b1;
+			red_b2[row][wc] = t.b2;
+			red_i1[row][wc] = t.i1;
+			red_bad[row][wc] = bd;
+		}
+	}
+	__syncthreads();
+	if (tid < kMU && i0 + tid < a.users) {
+		Top2 t{red_b1[tid][0], red_b2[tid][0], red_i1[tid][0]};
+		const Top2 o{red_b1[tid][1], red_b2[tid][1], red_i1[tid][1]};
+		top2_merge(t, o);
+		const int bd = red_bad[tid][0] | red_bad[tid][1];
+		const double rmax = __longlong_as_double((long long) *a.rnorm_max_bits);
+		const double thr = a.thr_scale * a.lnorm[i0 + tid] * rmax + 1e-300;
+		const bool certain = !bd && (t.i1 < 0 || (t.b1 - t.b2) > thr);
+		if (certain) {
+			a.best[i0 + tid] = t.i1;
+		} else {
+			a.best[i0 + tid] = -2;
+			a.ulist[atomicAdd(a.ucount, 1)] = i0 + tid;
 		}
 	}
 }

@@ -263,3 +263,50 @@ def test_two_ranks_one_gpu_sharded_bench(capi):
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
     assert out["check"]["L_max_rel"] < 1e-9 and out["check"]["R_max_rel"] < 1e-9, out["check"]
+
+
+@pytest.mark.parametrize("impl", ["mfma", "exact"])
+def test_recommend_forms_agree_with_oracle(capi, orc, impl, monkeypatch):
+    """MFMA filter + exact certification vs the all-exact form vs the oracle, on shapes that cross every tile
+    edge (128-user blocks, 64-item tiles, K chunks of 16) and with planted exact ties."""
+    monkeypatch.setenv("MF_RECOMMEND_IMPL", impl)
+    for seed, (u, i, k) in enumerate([(1, 1, 1), (129, 65, 17), (300, 200, 100), (257, 130, 33), (64, 1000, 4)]):
+        rng = np.random.default_rng(40 + seed)
+        L = rng.standard_normal((u, k))
+        R = rng.standard_normal((i, k))
+        if i > 70:
+            R[i - 1] = R[0]          # exact duplicates: certified only by the exact pass, lowest index wins
+            R[67] = R[3]
+        d = random_instance(60 + seed, u, i, k, density=0.3, full_rows=(0,) if u > 1 else ())
+        plan = capi.Plan(u, i, k, 0.0, d["row"], d["col"], d["val"])
+        plan.upload(L, R)
+        best = plan.recommend()
+        info = plan.recommend_info()
+        plan.close()
+        assert np.array_equal(best, orc.recommend(orc.Instance(**d), L, R)), (impl, u, i, k)
+        assert info == -1 if impl == "exact" else info >= 0
+
+
+def test_mfma_certification_sends_near_ties_to_the_exact_pass(capi, orc):
+    """Scores closer than the rounding bound must not be decided by the matrix cores."""
+    u, i, k = 200, 300, 64
+    rng = np.random.default_rng(3)
+    L = rng.standard_normal((u, k))
+    R = rng.standard_normal((i, k))
+    R[200:] = R[:100] * (1 + 2.0 ** -52)     # 100 items one ulp-scale away from items 0..99
+    d = random_instance(2, u, i, k, density=0.05)
+    plan = capi.Plan(u, i, k, 0.0, d["row"], d["col"], d["val"])
+    plan.upload(L, R)
+    best = plan.recommend()
+    sent = plan.recommend_info()
+    plan.close()
+    assert np.array_equal(best, orc.recommend(orc.Instance(**d), L, R))
+    assert sent > 0
+    # and a well-separated instance sends (almost) nobody
+    R2 = rng.standard_normal((i, k))
+    plan = capi.Plan(u, i, k, 0.0, d["row"], d["col"], d["val"])
+    plan.upload(L, R2)
+    best = plan.recommend()
+    assert plan.recommend_info() <= 2
+    plan.close()
+    assert np.array_equal(best, orc.recommend(orc.Instance(**d), L, R2))
