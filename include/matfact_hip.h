@@ -136,6 +136,10 @@ int mf_plan_recommend(mf_plan *plan, int32_t *best);
 /* users the last mf_plan_recommend sent through the exact pass (-1 when the exact form ran for all) */
 int mf_plan_recommend_info(mf_plan *plan, int64_t *exact_pass_users);
 
+/* Dense predictions of this shard's users, B (user_count x items, row-major) = L R^T exactly as mat2d_prod
+ * (mat2d.c:100-113) forms them; for debug dumps of SMALL instances (user_count*items <= 2^26). */
+int mf_plan_predict(mf_plan *plan, double *B);
+
 int mf_plan_synchronize(mf_plan *plan);
 
 /* Per-launch device timing (HIP events on the plan's stream).  After mf_plan_timing(plan, 1) every

@@ -29,7 +29,7 @@ HIP_SYMBOLS = [
     "mf_plan_create", "mf_plan_destroy", "mf_plan_set_stream", "mf_plan_upload_factors",
     "mf_plan_download_factors", "mf_plan_iterate", "mf_plan_sweep_items", "mf_plan_sweep_users",
     "mf_plan_items_next", "mf_plan_items_current", "mf_plan_flip", "mf_plan_recommend", "mf_plan_recommend_info",
-    "mf_plan_synchronize",
+    "mf_plan_predict", "mf_plan_synchronize",
     "mf_plan_timing", "mf_plan_timing_read", "mf_plan_describe",
 ]
 HOST_SYMBOLS = [
@@ -108,6 +108,7 @@ def hip():
         lib.mf_plan_flip.argtypes = [P]
         lib.mf_plan_recommend.argtypes = [P, _i32p]
         lib.mf_plan_recommend_info.argtypes = [P, C.POINTER(C.c_int64)]
+        lib.mf_plan_predict.argtypes = [P, _f64p]
         lib.mf_plan_synchronize.argtypes = [P]
         lib.mf_plan_timing.argtypes = [P, C.c_int]
         lib.mf_plan_timing_read.argtypes = [P, C.POINTER(C.c_int64), C.POINTER(C.c_double),
@@ -364,6 +365,11 @@ class Plan:
         n = C.c_int64()
         _check(hip().mf_plan_recommend_info(self._h, C.byref(n)), "mf_plan_recommend_info")
         return n.value
+
+    def predict(self):
+        B = np.empty((self.user_count, self.items), np.float64)
+        _check(hip().mf_plan_predict(self._h, B), "mf_plan_predict")
+        return B
 
     def synchronize(self):
         _check(hip().mf_plan_synchronize(self._h), "mf_plan_synchronize")

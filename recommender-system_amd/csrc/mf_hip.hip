@@ -563,6 +563,29 @@ int mf_plan_recommend_info(mf_plan *p, int64_t *exact_pass_users)
 	return MF_OK;
 }
 
+int mf_plan_predict(mf_plan *p, double *B)
+{
+	if (!p || !B) return MF_ERR_ARGUMENT;
+	if (!p->have_factors) return MF_ERR_STATE;
+	const size_t n = (size_t) p->uc * (size_t) p->items;
+	if (n > ((size_t) 1 << 26)) return MF_ERR_UNSUPPORTED;
+	if (n == 0) return MF_OK;
+	MF_HIP(hipSetDevice(p->device));
+	double *dB = nullptr;
+	MF_HIP(hipMalloc((void **) &dB, n * sizeof(double)));
+	hipLaunchKernelGGL(mf::predict_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, p->stream,
+	                   p->Lbuf[p->cur], p->Rbuf[p->cur], p->uc, p->items, p->K, dB);
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) e = hipMemcpyAsync(B, dB, n * sizeof(double), hipMemcpyDeviceToHost, p->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+	(void) hipFree(dB);
+	if (e != hipSuccess) {
+		g_last_hip_error = std::string("mf_plan_predict: ") + hipGetErrorString(e);
+		return MF_ERR_HIP;
+	}
+	return MF_OK;
+}
+
 int mf_plan_synchronize(mf_plan *p)
 {
 	if (!p) return MF_ERR_ARGUMENT;

@@ -429,6 +429,19 @@ __global__ void __launch_bounds__(256) recommend_kernel(RecArgs a)
 }
 
 
+// Dense B = L R^T (mat2d_prod, mat2d.c:100-113) for the debug dump of small instances: one thread per
+// (i, j), sequential k from 0.0, separate multiply and add -- every element equals the reference's B[i][j].
+__global__ void __launch_bounds__(256) predict_kernel(const double *__restrict__ L, const double *__restrict__ R,
+                                                      int users, int items, int K, double *__restrict__ B)
+{
+	const size_t t = (size_t) blockIdx.x * 256 + threadIdx.x;
+	if (t >= (size_t) users * items) return;
+	const double *l = L + (t / items) * K, *r = R + (t % items) * K;
+	double b = 0.0;
+	for (int k = 0; k < K; ++k) b = b + l[k] * r[k];
+	B[t] = b;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Recommend kernel, MFMA form: scores on the FP64 matrix cores, answers certified exact.
 //   pass 1 (this kernel)  S~ = L_blk * R^T with v_mfma_f64_16x16x4_f64; per user the best and the

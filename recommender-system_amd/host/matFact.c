@@ -13,7 +13,78 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <time.h>
+
+/*
+ * MATFACT_MATS=<path>: also write the reference's debug dump format (samples/inst{0,1,2}.mats): the dense
+ * rating matrix, then L, R (printed K x I, i.e. un-transposed) and B = L R^T with "%f " per element -- initially,
+ * after each of the first MATFACT_MATS_ITERS iterations (default 0; inst0.mats holds 5) and at the end.
+ * Uses the resident-plan API so that every number printed comes from the GPU path.
+ */
+static void mats_matrix(FILE *f, const char *title, const double *m, int rows, int cols, int transposed)
+{
+	fprintf(f, "%s\n", title);
+	for (int i = 0; i < rows; i++) {
+		for (int j = 0; j < cols; j++)
+			fprintf(f, "%f ", transposed ? m[(size_t) j * rows + i] : m[(size_t) i * cols + j]);
+		fprintf(f, "\n");
+	}
+}
+
+static int mats_state(FILE *f, mf_plan *plan, const mf_problem *p, double *L, double *R, double *B, int initial)
+{
+	int rc = mf_plan_download_factors(plan, L, R);
+	if (rc == MF_OK) rc = mf_plan_predict(plan, B);
+	if (rc != MF_OK) return rc;
+	mats_matrix(f, initial ? "Initial matrix L" : "Matrix L", L, p->users, p->features, 0);
+	mats_matrix(f, initial ? "Initial matrix R" : "Matrix R", R, p->features, p->items, 1);
+	mats_matrix(f, initial ? "Initial matrix B" : "Matrix B", B, p->users, p->items, 0);
+	return MF_OK;
+}
+
+static int run_with_mats(const char *path, const mf_problem *p, double *L, double *R, int32_t *best, int device)
+{
+	FILE *f = fopen(path, "w");
+	if (!f) return MF_ERR_ARGUMENT;
+	const size_t nb = (size_t) p->users * (size_t) p->items;
+	double *B = calloc(nb ? nb : 1, sizeof(double));
+	int32_t *row = malloc(sizeof(int32_t) * (size_t) (p->nnz ? p->nnz : 1));
+	int32_t *col = malloc(sizeof(int32_t) * (size_t) (p->nnz ? p->nnz : 1));
+	double *val = malloc(sizeof(double) * (size_t) (p->nnz ? p->nnz : 1));
+	if (!B || !row || !col || !val) return MF_ERR_NO_MEMORY;
+	mf_host_split_entries(p->entries, p->nnz, row, col, val);
+	for (int64_t n = 0; n < p->nnz; n++) B[(size_t) row[n] * p->items + col[n]] = val[n];
+	mats_matrix(f, "Initial matrix A", B, p->users, p->items, 0);
+
+	mf_shard s = {p->users, p->items, p->features, 0, p->users, p->nnz, row, col, val, p->alpha, device, 0, {0, 0}};
+	mf_plan *plan = NULL;
+	int rc = mf_plan_create(&plan, &s);
+	if (rc == MF_OK) rc = mf_plan_upload_factors(plan, L, R);
+	if (rc == MF_OK) rc = mats_state(f, plan, p, L, R, B, 1);
+	int shown = getenv("MATFACT_MATS_ITERS") ? atoi(getenv("MATFACT_MATS_ITERS")) : 0;
+	if (shown > p->iters) shown = p->iters;
+	for (int it = 0; rc == MF_OK && it < shown; it++) {
+		rc = mf_plan_iterate(plan, 1);
+		if (rc == MF_OK) {
+			fprintf(f, "Iter=%d\n", it);
+			rc = mats_state(f, plan, p, L, R, B, 0);
+		}
+	}
+	if (rc == MF_OK) rc = mf_plan_iterate(plan, p->iters - shown);
+	if (rc == MF_OK) {
+		fprintf(f, "Final:\n");
+		rc = mats_state(f, plan, p, L, R, B, 0);
+	}
+	if (rc == MF_OK) rc = mf_plan_recommend(plan, best);
+	mf_plan_destroy(plan);
+	free(B);
+	free(row);
+	free(col);
+	free(val);
+	if (fclose(f) == EOF && rc == MF_OK) rc = MF_ERR_ARGUMENT;
+	return rc;
+}
 
 /* util.c:7-10 */
 static void die(const char *error)
@@ -53,7 +124,8 @@ int main(int argc, char **argv)
 
 	int device = 0;
 	if (getenv("MATFACT_DEVICE")) device = atoi(getenv("MATFACT_DEVICE"));
-	const int rc = mf_backend_run(&prob, L, R, best, device);
+	const char *mats = getenv("MATFACT_MATS");
+	const int rc = mats ? run_with_mats(mats, &prob, L, R, best, device) : mf_backend_run(&prob, L, R, best, device);
 	if (rc != MF_OK) {
 		fprintf(stderr, "matFact (hip backend): %s %s\n", mf_backend_strerror(rc),
 		        rc == MF_ERR_HIP ? mf_backend_last_hip_error() : "");
