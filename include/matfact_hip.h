@@ -78,6 +78,13 @@ int mf_backend_recommend(const mf_problem *p, const double *L, const double *R, 
  * (either may be NULL if the caller does not want them back). */
 int mf_backend_run(const mf_problem *p, double *L, double *R, int32_t *best, int device);
 
+/* The same on several GPUs of ONE process: users are cut into ndev contiguous blocks balanced by entry count,
+ * L blocks are private, R is replicated and summed after every item sweep by a peer-to-peer reduce over xGMI
+ * (the decomposition of matFact-mpi.c:155-214 with the 8x1 grid of mpiutil.c:54-88).  devices[] lists HIP
+ * ordinals; an ordinal may repeat (several shards on one GPU -- how the path is tested on a one-GPU box).
+ * Peer access between distinct devices is required (MF_ERR_UNSUPPORTED otherwise).  ndev <= 16. */
+int mf_backend_run_multi(const mf_problem *p, double *L, double *R, int32_t *best, const int *devices, int ndev);
+
 /* ------------------------------------------------------------------------------------------ LEVEL 2 */
 
 typedef struct mf_plan mf_plan;

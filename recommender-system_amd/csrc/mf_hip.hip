@@ -681,6 +681,132 @@ int mf_backend_run(const mf_problem *pr, double *L, double *R, int32_t *best, in
 	return rc;
 }
 
+int mf_backend_run_multi(const mf_problem *pr, double *L, double *R, int32_t *best, const int *devices, int ndev)
+{
+	if (!pr || !L || !R || !devices || ndev < 1 || ndev > mf::kMaxShards || pr->users < 0 || pr->items < 0 ||
+	    pr->features < 1 || pr->nnz < 0 || pr->iters < 0 || (pr->nnz > 0 && !pr->entries))
+		return MF_ERR_ARGUMENT;
+	if (ndev == 1) return mf_backend_run(pr, L, R, best, devices[0]);
+	const int total = mf_backend_device_count();
+	if (total <= 0) return MF_ERR_NO_DEVICE;
+	for (int g = 0; g < ndev; ++g)
+		if (devices[g] < 0 || devices[g] >= total) return MF_ERR_NO_DEVICE;
+	const int U = pr->users, I = pr->items, K = pr->features;
+	for (int64_t n = 0; n < pr->nnz; ++n)
+		if (pr->entries[n].row < 0 || pr->entries[n].row >= U) return MF_ERR_ARGUMENT;
+
+	// ---- user blocks balanced by entry count (cut at row boundaries)
+	std::vector<int64_t> cnt((size_t) U + 1, 0);
+	for (int64_t n = 0; n < pr->nnz; ++n) cnt[(size_t) pr->entries[n].row + 1]++;
+	for (int u = 0; u < U; ++u) cnt[(size_t) u + 1] += cnt[u];
+	std::vector<int> begin((size_t) ndev + 1, 0);
+	{
+		int u = 0;
+		for (int g = 1; g < ndev; ++g) {
+			const int64_t target = cnt[U] * g / ndev;
+			while (u < U && cnt[u] < target) ++u;
+			begin[g] = u;
+		}
+		begin[ndev] = U;
+	}
+	// ---- peer access between distinct devices
+	for (int g = 0; g < ndev; ++g)
+		for (int h = 0; h < ndev; ++h)
+			if (devices[g] != devices[h]) {
+				int can = 0;
+				MF_HIP(hipDeviceCanAccessPeer(&can, devices[g], devices[h]));
+				if (!can) return MF_ERR_UNSUPPORTED;
+				MF_HIP(hipSetDevice(devices[g]));
+				const hipError_t e = hipDeviceEnablePeerAccess(devices[h], 0);
+				if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) MF_HIP(e);
+				(void) hipGetLastError();
+			}
+
+	std::vector<mf_plan *> plan((size_t) ndev, nullptr);
+	std::vector<hipEvent_t> ev_items((size_t) ndev, nullptr), ev_red((size_t) ndev, nullptr);
+	int rc = MF_OK;
+	auto cleanup = [&]() {
+		for (int g = 0; g < ndev; ++g) {
+			if (plan[g]) (void) hipSetDevice(plan[g]->device);
+			if (ev_items[g]) (void) hipEventDestroy(ev_items[g]);
+			if (ev_red[g]) (void) hipEventDestroy(ev_red[g]);
+			mf_plan_destroy(plan[g]);
+		}
+	};
+	// ---- one resident plan per shard (entries filtered in file order)
+	for (int g = 0; g < ndev && rc == MF_OK; ++g) {
+		std::vector<int32_t> row, col;
+		std::vector<double> val;
+		for (int64_t n = 0; n < pr->nnz; ++n) {
+			const mf_entry &e = pr->entries[n];
+			if (e.row >= begin[g] && e.row < begin[g + 1]) {
+				row.push_back(e.row);
+				col.push_back(e.col);
+				val.push_back(e.value);
+			}
+		}
+		mf_shard s;
+		memset(&s, 0, sizeof s);
+		s.users_total = U;
+		s.items = I;
+		s.features = K;
+		s.user_begin = begin[g];
+		s.user_count = begin[g + 1] - begin[g];
+		s.nnz = (int64_t) row.size();
+		s.row = row.data();
+		s.col = col.data();
+		s.val = val.data();
+		s.alpha = pr->alpha;
+		s.device = devices[g];
+		rc = mf_plan_create(&plan[g], &s);
+		if (rc == MF_OK) rc = mf_plan_upload_factors(plan[g], L + (size_t) begin[g] * K, R);
+		if (rc == MF_OK) {
+			if (hipEventCreateWithFlags(&ev_items[g], hipEventDisableTiming) != hipSuccess ||
+			    hipEventCreateWithFlags(&ev_red[g], hipEventDisableTiming) != hipSuccess)
+				rc = MF_ERR_HIP;
+		}
+	}
+	// ---- iterations: item sweep (shard 0 seeds from the old factor, matFact-mpi.c:187) -> user sweep ->
+	//      wait for every shard's item sweep -> reduce my slice over all buffers -> wait for every reduce -> flip
+	const size_t nr = (size_t) I * K;
+	for (int it = 0; it < pr->iters && rc == MF_OK; ++it) {
+		for (int g = 0; g < ndev && rc == MF_OK; ++g) {
+			rc = mf_plan_sweep_items(plan[g], g == 0);
+			if (rc == MF_OK && hipEventRecord(ev_items[g], plan[g]->stream) != hipSuccess) rc = MF_ERR_HIP;
+			if (rc == MF_OK) rc = mf_plan_sweep_users(plan[g]);
+		}
+		for (int g = 0; g < ndev && rc == MF_OK; ++g) {
+			(void) hipSetDevice(plan[g]->device);
+			for (int h = 0; h < ndev; ++h)
+				if (h != g && hipStreamWaitEvent(plan[g]->stream, ev_items[h], 0) != hipSuccess) rc = MF_ERR_HIP;
+			mf::PeerReduceArgs a;
+			a.nshards = ndev;
+			for (int h = 0; h < ndev; ++h) a.buf[h] = plan[h]->Rbuf[plan[h]->cur ^ 1];
+			a.begin = ((nr / 2) * g / ndev) * 2;
+			a.end = g == ndev - 1 ? nr : ((nr / 2) * (g + 1) / ndev) * 2;
+			if (a.end > a.begin && rc == MF_OK) {
+				const size_t pairs = (a.end - a.begin + 1) / 2;
+				const unsigned grid = (unsigned) std::min<size_t>((pairs + 255) / 256, 2048);
+				hipLaunchKernelGGL(mf::peer_allreduce_kernel, dim3(grid), dim3(256), 0, plan[g]->stream, a);
+				if (hipGetLastError() != hipSuccess) rc = MF_ERR_HIP;
+			}
+			if (rc == MF_OK && hipEventRecord(ev_red[g], plan[g]->stream) != hipSuccess) rc = MF_ERR_HIP;
+		}
+		for (int g = 0; g < ndev && rc == MF_OK; ++g) {
+			(void) hipSetDevice(plan[g]->device);
+			for (int h = 0; h < ndev; ++h)
+				if (h != g && hipStreamWaitEvent(plan[g]->stream, ev_red[h], 0) != hipSuccess) rc = MF_ERR_HIP;
+			mf_plan_flip(plan[g]);
+		}
+	}
+	for (int g = 0; g < ndev && rc == MF_OK; ++g) rc = mf_plan_synchronize(plan[g]);
+	for (int g = 0; g < ndev && rc == MF_OK && best; ++g) rc = mf_plan_recommend(plan[g], best + begin[g]);
+	for (int g = 0; g < ndev && rc == MF_OK; ++g)
+		rc = mf_plan_download_factors(plan[g], L + (size_t) begin[g] * K, g == 0 ? R : nullptr);
+	cleanup();
+	return rc;
+}
+
 int mf_backend_factorize(const mf_problem *pr, double *L, double *R, int device)
 {
 	return mf_backend_run(pr, L, R, nullptr, device);

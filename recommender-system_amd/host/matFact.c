@@ -125,7 +125,22 @@ int main(int argc, char **argv)
 	int device = 0;
 	if (getenv("MATFACT_DEVICE")) device = atoi(getenv("MATFACT_DEVICE"));
 	const char *mats = getenv("MATFACT_MATS");
-	const int rc = mats ? run_with_mats(mats, &prob, L, R, best, device) : mf_backend_run(&prob, L, R, best, device);
+	const char *devlist = getenv("MATFACT_DEVICES");   /* e.g. "0,1,2,3,4,5,6,7": row-shard over these GPUs */
+	int rc;
+	if (mats) {
+		rc = run_with_mats(mats, &prob, L, R, best, device);
+	} else if (devlist) {
+		int devs[16], nd = 0;
+		for (const char *c = devlist; *c && nd < 16;) {
+			char *stop;
+			devs[nd++] = (int) strtol(c, &stop, 10);
+			if (stop == c) die("MATFACT_DEVICES: expected a comma-separated list of device ordinals.");
+			c = *stop == ',' ? stop + 1 : stop;
+		}
+		rc = mf_backend_run_multi(&prob, L, R, best, devs, nd);
+	} else {
+		rc = mf_backend_run(&prob, L, R, best, device);
+	}
 	if (rc != MF_OK) {
 		fprintf(stderr, "matFact (hip backend): %s %s\n", mf_backend_strerror(rc),
 		        rc == MF_ERR_HIP ? mf_backend_last_hip_error() : "");

@@ -344,3 +344,35 @@ def test_plan_predict_equals_oracle_rows(capi, orc):
     plan.close()
     for i in (0, 17, 36):
         assert np.array_equal(B[i], orc.predict_row(L[i], R))
+
+
+def test_single_process_multi_shard_run(capi, orc, tmp_path):
+    """mf_backend_run_multi with several shards placed on the one GPU of this box: the same code path as one
+    shard per GPU (per-shard plans, event-ordered peer reduce of the item factor, gather of the results)."""
+    d = random_instance(91, 230, 140, 30, density=0.25, iters=12, alpha=0.002, empty_rows=(3, 100), full_rows=(8,))
+    Lo, Ro, bo = _oracle_run(orc, d)
+    for nd in (2, 3, 5):
+        L, R = capi.init_factors(230, 140, 30)
+        best = capi.backend_run_multi(_inst(capi, d), L, R, [0] * nd)
+        # only the nd-way re-association of the sum into R differs from the serial order
+        assert np.allclose(L, Lo, rtol=1e-9, atol=1e-13) and np.allclose(R, Ro, rtol=1e-9, atol=1e-13), nd
+        assert np.array_equal(best, bo), nd
+    # one shard == the single-GPU entry point, bit for bit
+    L, R = capi.init_factors(230, 140, 30)
+    best = capi.backend_run_multi(_inst(capi, d), L, R, [0])
+    assert np.array_equal(L, Lo) and np.array_equal(R, Ro) and np.array_equal(best, bo)
+    # reproducible: the peer reduce sums in a fixed shard order
+    L1, R1 = capi.init_factors(230, 140, 30)
+    L2, R2 = capi.init_factors(230, 140, 30)
+    capi.backend_run_multi(_inst(capi, d), L1, R1, [0, 0, 0])
+    capi.backend_run_multi(_inst(capi, d), L2, R2, [0, 0, 0])
+    assert np.array_equal(L1, L2) and np.array_equal(R1, R2)
+    # through the CLI
+    p = tmp_path / "m.in"
+    p.write_text(to_text(d))
+    r = subprocess.run([capi.CLI_PATH, str(p)], capture_output=True, env=dict(os.environ, MATFACT_DEVICES="0,0,0,0"))
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.decode() == "".join("%d\n" % b for b in bo if b >= 0)
+    with pytest.raises(capi.HipBackendError) as e:
+        capi.backend_run_multi(_inst(capi, d), L, R, [0, 7])
+    assert e.value.status == capi.MF_ERR_NO_DEVICE
