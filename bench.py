@@ -142,11 +142,13 @@ def main():
     plan = capi.Plan(U, I, K, cfg["alpha"], row, col, val, user_begin=u0, user_count=uc, device=local_dev,
                      items_ext=[t.data_ptr() for t in r_bufs])
     del row, col, val
-    stream = torch.cuda.current_stream()
-    plan.set_stream(stream.cuda_stream)
+    # one explicit stream carries the sweeps AND the collective (the default stream's handle 0 means
+    # "plan's own stream" to mf_plan_set_stream, which the collective would not be ordered against)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    run = rs.sharded.ShardedFactorization(plan, r_bufs, rank, world, overlap=not args.no_overlap, stream=stream)
     plan.upload(Lb, R0)
     del Lb, R0
-    run = rs.sharded.ShardedFactorization(plan, r_bufs, rank, world, overlap=not args.no_overlap)
     t_setup = time.time() - t_setup
 
     def fence():

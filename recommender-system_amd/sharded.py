@@ -27,10 +27,20 @@ def shard_bounds(users, world, row_ptr=None, by_entries=True):
 class ShardedFactorization:
     """Runs iterations of one shard and keeps the two R generations in torch tensors for the collective."""
 
-    def __init__(self, plan, r_buffers, rank, world, group=None, overlap=True):
+    def __init__(self, plan, r_buffers, rank, world, group=None, overlap=True, stream=None):
+        """`stream`: a NON-default torch.cuda.Stream for GPU runs.  The plan's kernels and the collective must be
+        ordered on the same stream; the default stream's handle is 0, which mf_plan_set_stream reads as "use the
+        plan's own stream", so it cannot be used here.  None only for CPU stand-in plans (tests)."""
         self.plan, self.rank, self.world, self.group, self.overlap = plan, rank, world, group, overlap
         self.r = list(r_buffers)          # two tensors, items x K, same device as the plan
         self._ptr = {int(t.data_ptr()): t for t in self.r}
+        self.stream = stream
+        if stream is not None:
+            if int(stream.cuda_stream) == 0:
+                raise ValueError("ShardedFactorization needs a non-default CUDA stream")
+            plan.set_stream(int(stream.cuda_stream))
+        elif self.r[0].is_cuda:
+            raise ValueError("GPU buffers need an explicit stream")
 
     def _next_tensor(self):
         return self._ptr[int(self.plan.items_next_ptr())]
@@ -39,6 +49,13 @@ class ShardedFactorization:
         return self._ptr[int(self.plan.items_current_ptr())]
 
     def step(self):
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                self._step()
+        else:
+            self._step()
+
+    def _step(self):
         p = self.plan
         if self.world == 1:
             p.sweep_items(True)
