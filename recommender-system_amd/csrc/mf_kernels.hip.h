@@ -528,7 +528,11 @@ __global__ void __launch_bounds__(kWave) row_norm_kernel(const double *__restric
 }
 
 constexpr int kMU = 128, kMI = 128, kMKC = 32;
-constexpr int kMLD = 128 + 16;   // k-major rows of 144 doubles: lanes 16..31 of a read land 32 banks further
+// LDS image of a chunk: [k-pair][row] of double2 {x[row][2p], x[row][2p+1]}, 130 rows per k-pair.
+//   fragment read (ds_read_b64): lanes 0..31 = 16 rows x (k, k+1) of one pair -> 256 contiguous bytes;
+//   staging store (ds_write_b128): an 8-lane group = 2 rows x 4 k-pairs, pair stride 130*16 B = 8 banks mod 32.
+// Both are bank-conflict-free (the first version's [k][row] image conflicted 4-way on the stores).
+constexpr int kMLD2 = 130;
 constexpr int kMThreads = 512;
 
 struct Top2 {
@@ -554,8 +558,8 @@ typedef double mf_d4 __attribute__((ext_vector_type(4)));
 template <bool VEC>   // VEC: K even -> rows are 16-B aligned, 16-byte global loads
 __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a)
 {
-	__shared__ double As[kMKC][kMLD];
-	__shared__ double Bs[kMKC][kMLD];
+	__shared__ double2 As[2][kMKC / 2][kMLD2];   // double-buffered: one barrier per chunk
+	__shared__ double2 Bs[2][kMKC / 2][kMLD2];
 	__shared__ unsigned long long maskw[kMU][2];
 	__shared__ double red_b1[kMU][2], red_b2[kMU][2];
 	__shared__ int red_i1[kMU][2], red_bad[kMU][2];
@@ -586,39 +590,43 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 		i1[x] = -1;
 	}
 
-	// staging roles: A and B chunks are 128 rows x 32 k, 8 consecutive doubles per thread
-	constexpr int SN = 8;
-	const int srow = tid >> 2, sk = (tid & 3) * SN;
+	// staging roles: A and B chunks are 128 rows x 32 k; thread -> row tid/4, k-pairs 4m + (tid%4), m = 0..3
+	constexpr int SP = kMKC / 8;
+	const int srow = tid >> 2, sq = tid & 3;
 	const bool a_ok = i0 + srow < a.users;
 	const double *__restrict__ aptr = a.L + (size_t) (a_ok ? i0 + srow : 0) * K;
-	double av[SN], bv[SN];
+	double2 av[SP], bv[SP];
 
 	// global -> registers for chunk (tile jt, k offset kc); zero outside the matrices
 	auto fetch = [&](int jt, int kc) {
 		const bool b_ok = jt + srow < a.items;
 		const double *__restrict__ bptr = a.R + (size_t) (b_ok ? jt + srow : 0) * K;
-		if (VEC) {
 #pragma unroll
-			for (int x = 0; x < SN; x += 2) {
-				const int k = kc + sk + x;
-				const double2 va = (a_ok && k < K) ? *reinterpret_cast<const double2 *>(aptr + k) : make_double2(0.0, 0.0);
-				const double2 vb = (b_ok && k < K) ? *reinterpret_cast<const double2 *>(bptr + k) : make_double2(0.0, 0.0);
-				av[x] = va.x;
-				av[x + 1] = va.y;
-				bv[x] = vb.x;
-				bv[x + 1] = vb.y;
-			}
-		} else {
-#pragma unroll
-			for (int x = 0; x < SN; ++x) {
-				const int k = kc + sk + x;
-				av[x] = (a_ok && k < K) ? aptr[k] : 0.0;
-				bv[x] = (b_ok && k < K) ? bptr[k] : 0.0;
+		for (int m = 0; m < SP; ++m) {
+			const int k = kc + 8 * m + 2 * sq;
+			if (VEC) {
+				av[m] = (a_ok && k < K) ? *reinterpret_cast<const double2 *>(aptr + k) : make_double2(0.0, 0.0);
+				bv[m] = (b_ok && k < K) ? *reinterpret_cast<const double2 *>(bptr + k) : make_double2(0.0, 0.0);
+			} else {
+				av[m].x = (a_ok && k < K) ? aptr[k] : 0.0;
+				av[m].y = (a_ok && k + 1 < K) ? aptr[k + 1] : 0.0;
+				bv[m].x = (b_ok && k < K) ? bptr[k] : 0.0;
+				bv[m].y = (b_ok && k + 1 < K) ? bptr[k + 1] : 0.0;
 			}
 		}
 	};
+	auto stage = [&](int buf) {
+#pragma unroll
+		for (int m = 0; m < SP; ++m) {
+			As[buf][4 * m + sq][srow] = av[m];
+			Bs[buf][4 * m + sq][srow] = bv[m];
+		}
+	};
 
+	int buf = 0;
 	fetch(0, 0);
+	stage(0);
+	__syncthreads();
 	for (int j0 = 0; j0 < a.items; j0 += kMI) {
 		mf_d4 acc[2][4];
 #pragma unroll
@@ -627,24 +635,22 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 			for (int ti = 0; ti < 4; ++ti) acc[tu][ti] = mf_d4{0.0, 0.0, 0.0, 0.0};
 
 		for (int kc = 0; kc < K; kc += kMKC) {
-			__syncthreads();   // previous chunk's fragment reads are done
-#pragma unroll
-			for (int x = 0; x < SN; ++x) {
-				As[sk + x][srow] = av[x];
-				Bs[sk + x][srow] = bv[x];
-			}
-			__syncthreads();
-			// prefetch the next chunk (of this tile, or the first of the next tile) behind the MFMAs
+			// next chunk (of this tile, or the first of the next tile): global loads fly behind the MFMAs
+			const bool more = kc + kMKC < K || j0 + kMI < a.items;
 			if (kc + kMKC < K)
 				fetch(j0, kc + kMKC);
 			else if (j0 + kMI < a.items)
 				fetch(j0 + kMI, 0);
+			const double *Ab = reinterpret_cast<const double *>(&As[buf][0][0]);
+			const double *Bb = reinterpret_cast<const double *>(&Bs[buf][0][0]);
 			auto kstep = [&](int ks) {
+				// k = 4*ks + lq -> pair 2*ks + (lq >> 1), half lq & 1
+				const int po = ((2 * ks + (lq >> 1)) * kMLD2) * 2 + (lq & 1);
 				double fa[2], fb[4];
 #pragma unroll
-				for (int tu = 0; tu < 2; ++tu) fa[tu] = As[ks * 4 + lq][32 * wr + 16 * tu + lr];
+				for (int tu = 0; tu < 2; ++tu) fa[tu] = Ab[po + (32 * wr + 16 * tu + lr) * 2];
 #pragma unroll
-				for (int ti = 0; ti < 4; ++ti) fb[ti] = Bs[ks * 4 + lq][64 * wc + 16 * ti + lr];
+				for (int ti = 0; ti < 4; ++ti) fb[ti] = Bb[po + (64 * wc + 16 * ti + lr) * 2];
 #pragma unroll
 				for (int tu = 0; tu < 2; ++tu)
 #pragma unroll
@@ -658,6 +664,10 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 				const int ksteps = (K - kc + 3) >> 2;
 				for (int ks = 0; ks < ksteps; ++ks) kstep(ks);
 			}
+			// registers -> the OTHER buffer (last read one chunk ago; every wave passed a barrier since)
+			if (more) stage(buf ^ 1);
+			__syncthreads();
+			buf ^= 1;
 		}
 
 		// rated-item mask of this tile: bit jj of word w = item j0 + 64*w + jj is rated or beyond the last item
