@@ -103,6 +103,8 @@ struct mf_plan {
 	SweepVariant sweep{};
 	int nch = 0, stride = 0;
 	size_t lds_bytes = 0;
+	int nch_few = 0;            // chunk size when a sweep has too few rows to fill the chip (see choose_sweep)
+	size_t lds_bytes_few = 0;
 
 	bool timing = false;
 	std::vector<TimedLaunch> timed;
@@ -154,8 +156,14 @@ int choose_sweep(mf_plan *p)
 	if (nch < 1) return MF_ERR_UNSUPPORTED;
 	p->nch = nch;
 	p->lds_bytes = head + (size_t) nch * row_bytes;
+	// A sweep over FEW rows (ML100k: 943 x 1682) cannot fill 256 CUs whatever the chunk size; its time is the
+	// longest row's serial chain of chunks, so use the largest chunk there (737 entries: 47 -> 12 chunks).
+	int few = std::max(nch, std::min(64, fit(kLdsPerCu / 2)));
+	if (getenv("MF_SWEEP_NCH")) few = nch;
+	p->nch_few = few;
+	p->lds_bytes_few = head + (size_t) few * row_bytes;
 	MF_HIP(hipFuncSetAttribute((const void *) p->sweep.fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-	                           (int) p->lds_bytes));
+	                           (int) std::max(p->lds_bytes, p->lds_bytes_few)));
 	return MF_OK;
 }
 
@@ -212,6 +220,9 @@ int launch_sweep(mf_plan *p, int kind, int seed)
 		a.X_new = p->Lbuf[nxt];
 	}
 	if (a.nrows <= 0) return MF_OK;
+	const bool few_rows = a.nrows < 4096;
+	if (few_rows) a.nch = p->nch_few;
+	const size_t lds = few_rows ? p->lds_bytes_few : p->lds_bytes;
 	const int grid = std::min(a.nrows, 1 << 20);
 	TimedLaunch t{};
 	if (p->timing) {
@@ -221,8 +232,7 @@ int launch_sweep(mf_plan *p, int kind, int seed)
 		MF_HIP(hipEventRecord(t.t0, p->stream));
 	}
 	void *args[] = {&a};
-	MF_HIP(hipLaunchKernel((const void *) p->sweep.fn, dim3(grid), dim3(mf::kWave), args, p->lds_bytes,
-	                       p->stream));
+	MF_HIP(hipLaunchKernel((const void *) p->sweep.fn, dim3(grid), dim3(mf::kWave), args, lds, p->stream));
 	if (p->timing) {
 		MF_HIP(hipEventRecord(t.t1, p->stream));
 		p->timed.push_back(t);
