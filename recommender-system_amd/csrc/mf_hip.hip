@@ -33,18 +33,20 @@ struct SweepVariant {
 	int dma;        // 1: LDS-DMA form
 	int row_bytes;  // LDS tile row stride in bytes (DMA form)
 	int xs_bytes;   // LDS bytes in front of the tile (DMA form)
+	SweepFn coop;   // row-cooperative form for launches with few rows (DMA variants only)
 };
 
 template <int KT, int KP>
 constexpr SweepVariant variant()
 {
-	return SweepVariant{mf::sweep_kernel<KT, KP>, KT, KP, 0, 0, 0};
+	return SweepVariant{mf::sweep_kernel<KT, KP>, KT, KP, 0, 0, 0, nullptr};
 }
 
 template <int KT>
 constexpr SweepVariant dma_variant()
 {
-	return SweepVariant{mf::sweep_dma_kernel<KT>, KT, 0, 1, mf::DmaGeom<KT>::kStride, mf::DmaGeom<KT>::kXsBytes};
+	return SweepVariant{mf::sweep_dma_kernel<KT>, KT, 0, 1, mf::DmaGeom<KT>::kStride, mf::DmaGeom<KT>::kXsBytes,
+	                    mf::sweep_coop_kernel<KT>};
 }
 
 // K-specialised instances for the K of the bundled samples and of the BASELINE configs, then generic ones.
@@ -105,6 +107,9 @@ struct mf_plan {
 	size_t lds_bytes = 0;
 	int nch_few = 0;            // chunk size when a sweep has too few rows to fill the chip (see choose_sweep)
 	size_t lds_bytes_few = 0;
+	int nch_coop = 0;           // chunk size of the row-cooperative form (0: not available)
+	size_t lds_bytes_coop = 0;
+	int max_row_len[2] = {0, 0}; // longest column (item sweep) / longest user row (user sweep)
 
 	bool timing = false;
 	std::vector<TimedLaunch> timed;
@@ -117,7 +122,7 @@ namespace {
 int choose_sweep(mf_plan *p)
 {
 	const int K = p->K;
-	p->sweep = SweepVariant{nullptr, 0, 0, 0, 0, 0};
+	p->sweep = SweepVariant{nullptr, 0, 0, 0, 0, 0, nullptr};
 	const char *impl = getenv("MF_SWEEP_IMPL");   // "dma" (default) | "reg": register-staged form only
 	const bool allow_dma = !(impl && strcmp(impl, "reg") == 0);
 	if (allow_dma)
@@ -164,6 +169,26 @@ int choose_sweep(mf_plan *p)
 	p->lds_bytes_few = head + (size_t) few * row_bytes;
 	MF_HIP(hipFuncSetAttribute((const void *) p->sweep.fn, hipFuncAttributeMaxDynamicSharedMemorySize,
 	                           (int) std::max(p->lds_bytes, p->lds_bytes_few)));
+	// row-cooperative form: 2 buffers x 7 producer tiles in ~110 KB, 4..32 entries per tile
+	p->nch_coop = 0;
+	const char *coop_env = getenv("MF_SWEEP_COOP");   // "0" disables
+	if (p->sweep.coop && !(coop_env && coop_env[0] == '0')) {
+		// ~48 KB of tiles per workgroup keeps 3 rows resident per CU (ML100k: 24-entry tiles 0.38 s, 32-entry
+		// tiles -- one workgroup per CU -- 0.55 s); below 8 entries per tile phase A's K steps dominate, so large
+		// K keeps the single-wave form with 64-entry chunks
+		const size_t per_entry = 2 * (size_t) mf::kCoopProducers * row_bytes;
+		int nc = (int) std::min<size_t>(32, (48 * 1024) / per_entry);
+		if (const char *env = getenv("MF_SWEEP_NCH")) {
+			const int v = atoi(env);
+			if (v >= 1 && v <= 64 && head + (size_t) v * per_entry <= kLdsPerCu) nc = v;
+		}
+		if (nc >= 8 || getenv("MF_SWEEP_NCH")) {
+			p->nch_coop = std::max(nc, 1);
+			p->lds_bytes_coop = head + (size_t) p->nch_coop * per_entry;
+			MF_HIP(hipFuncSetAttribute((const void *) p->sweep.coop, hipFuncAttributeMaxDynamicSharedMemorySize,
+			                           (int) p->lds_bytes_coop));
+		}
+	}
 	return MF_OK;
 }
 
@@ -221,8 +246,12 @@ int launch_sweep(mf_plan *p, int kind, int seed)
 	}
 	if (a.nrows <= 0) return MF_OK;
 	const bool few_rows = a.nrows < 4096;
-	if (few_rows) a.nch = p->nch_few;
-	const size_t lds = few_rows ? p->lds_bytes_few : p->lds_bytes;
+	// cooperative form only where a long row's serial walk is the launch time
+	const bool coop = few_rows && p->nch_coop > 0 && p->max_row_len[kind] >= 128;
+	if (few_rows) a.nch = coop ? p->nch_coop : p->nch_few;
+	const size_t lds = coop ? p->lds_bytes_coop : (few_rows ? p->lds_bytes_few : p->lds_bytes);
+	const SweepFn fn = coop ? p->sweep.coop : p->sweep.fn;
+	const int block = coop ? mf::kCoopWaves * mf::kWave : mf::kWave;
 	const int grid = std::min(a.nrows, 1 << 20);
 	TimedLaunch t{};
 	if (p->timing) {
@@ -232,7 +261,7 @@ int launch_sweep(mf_plan *p, int kind, int seed)
 		MF_HIP(hipEventRecord(t.t0, p->stream));
 	}
 	void *args[] = {&a};
-	MF_HIP(hipLaunchKernel((const void *) p->sweep.fn, dim3(grid), dim3(mf::kWave), args, lds, p->stream));
+	MF_HIP(hipLaunchKernel((const void *) fn, dim3(grid), dim3(block), args, lds, p->stream));
 	if (p->timing) {
 		MF_HIP(hipEventRecord(t.t1, p->stream));
 		p->timed.push_back(t);
@@ -347,6 +376,7 @@ int mf_plan_create(mf_plan **out, const mf_shard *s)
 			return fail(_e == hipErrorOutOfMemory ? MF_ERR_NO_MEMORY : MF_ERR_HIP);   \
 		}                                                                             \
 	} while (0)
+	for (int u = 0; u < p->uc; ++u) p->max_row_len[1] = std::max(p->max_row_len[1], ptr[(size_t) u + 1] - ptr[u]);
 	const size_t nz = (size_t) s->nnz;
 	MF_TRY(dev_alloc(&p->csr_ptr, (size_t) p->uc + 1));
 	MF_TRY(dev_alloc(&p->csr_idx, nz + 64));
@@ -361,6 +391,7 @@ int mf_plan_create(mf_plan **out, const mf_shard *s)
 	} catch (const std::bad_alloc &) {
 		return fail(MF_ERR_NO_MEMORY);
 	}
+	for (int j = 0; j < p->items; ++j) p->max_row_len[0] = std::max(p->max_row_len[0], ptr[(size_t) j + 1] - ptr[j]);
 	MF_TRY(dev_alloc(&p->csc_ptr, (size_t) p->items + 1));
 	MF_TRY(dev_alloc(&p->csc_idx, nz + 64));
 	MF_TRY(dev_alloc(&p->csc_val, nz + 64));
@@ -631,8 +662,8 @@ int mf_plan_describe(mf_plan *p, char *buf, int buflen)
 {
 	if (!p || !buf || buflen <= 0) return MF_ERR_ARGUMENT;
 	if (p->sweep.dma)
-		snprintf(buf, (size_t) buflen, "sweep_dma_kernel<KT=%d> K=%d nch=%d row_bytes=%d lds=%zu", p->sweep.kt,
-		         p->K, p->nch, p->sweep.row_bytes, p->lds_bytes);
+		snprintf(buf, (size_t) buflen, "sweep_dma_kernel<KT=%d> K=%d nch=%d row_bytes=%d lds=%zu coop_nch=%d",
+		         p->sweep.kt, p->K, p->nch, p->sweep.row_bytes, p->lds_bytes, p->nch_coop);
 	else
 		snprintf(buf, (size_t) buflen, "sweep_kernel<KT=%d,KPMAX=%d> K=%d nch=%d stride=%d lds=%zu",
 		         p->sweep.kt, p->sweep.kpmax, p->K, p->nch, p->stride, p->lds_bytes);

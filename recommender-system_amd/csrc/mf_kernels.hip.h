@@ -429,6 +429,157 @@ __global__ void __launch_bounds__(256) recommend_kernel(RecArgs a)
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Sweep kernel, row-cooperative form: for launches with FEW rows (ML100k: 943 users / 1682 items), where
+// one wave walking a long row alone (737 entries = 47 chunks) is the whole launch time.  A workgroup of
+// 8 waves owns one row.  Waves 1..7 ("producers") each take one chunk per round: LDS-DMA gather, phase A
+// (sequential-k dots -> e_n) and then SCALE their tile in place, p_n[k] = e_n * y_n[k] (the same rounded
+// product the serial loop forms).  Wave 0 (the "accumulator") only walks the finished tiles in entry order
+// doing acc[k] = acc[k] + p_n[k]: the serial chain per entry is one dependent add instead of a whole chunk
+// pipeline, while the producers already fill the other tile buffer for the next round (double-buffered,
+// one barrier per round).  Same arithmetic, same order: results stay bit-identical to the serial reference.
+// LDS: [ x row ][ 2 buffers x 7 producers x nch rows x S bytes ].
+// ------------------------------------------------------------------------------------------------
+constexpr int kCoopWaves = 8;
+constexpr int kCoopProducers = kCoopWaves - 1;
+
+template <int KT>
+__global__ void __launch_bounds__(kCoopWaves *kWave) sweep_coop_kernel(SweepArgs a)
+{
+	using G = DmaGeom<KT>;
+	constexpr int K = KT, P = G::kPieces, NP = G::kPasses, S = G::kStride;
+	extern __shared__ __attribute__((aligned(16))) char lds[];
+	double2 *xs = reinterpret_cast<double2 *>(lds);
+	const int nch = a.nch;
+	const int tile_bytes = nch * S;
+	char *tiles = lds + G::kXsBytes;   // tile(buf, p) = tiles + (buf * kCoopProducers + p) * tile_bytes
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const unsigned voff = (unsigned) lane * 16u;
+	const unsigned long long ybase = (unsigned long long) a.Y_old;
+	const int per_round = kCoopProducers * nch;
+
+	for (int r = blockIdx.x; r < a.nrows; r += gridDim.x) {
+		const int beg = a.ptr[r], end = a.ptr[r + 1];
+		const double2 *__restrict__ xrow2 = reinterpret_cast<const double2 *>(a.X_old + (size_t) r * K);
+		double2 acc[NP];
+#pragma unroll
+		for (int p = 0; p < NP; ++p) acc[p] = make_double2(0.0, 0.0);
+		if (wave == 0) {
+#pragma unroll
+			for (int p = 0; p < NP; ++p) {
+				const int q = lane + kWave * p;
+				if (q < P) {
+					const double2 v = xrow2[q];
+					xs[q] = v;
+					if (a.seed) acc[p] = v;
+				}
+			}
+		}
+		__syncthreads();
+		const int rounds = (end - beg + per_round - 1) / per_round;
+		for (int round = 0; round <= rounds; ++round) {
+			if (wave > 0) {
+				// ---- producer: chunk (round, wave-1) -> buffer round&1
+				const int c = beg + round * per_round + (wave - 1) * nch;
+				const int cnt = round < rounds ? max(0, min(nch, end - c)) : 0;
+				if (cnt > 0) {
+					char *tile = tiles + ((round & 1) * kCoopProducers + (wave - 1)) * tile_bytes;
+					int my_idx = 0;
+					double my_val = 0.0;
+					if (lane < cnt) {
+						my_idx = a.idx[c + lane];
+						my_val = a.val[c + lane];
+					}
+					for (int n = 0; n < cnt; ++n) {
+						const int j = __builtin_amdgcn_readlane(my_idx, n);
+						unsigned long long base = ybase + (unsigned long long) (unsigned) j * (unsigned long long) (K * 8);
+						asm volatile("" : "+s"(base));
+#pragma unroll
+						for (int p = 0; p < NP; ++p) {
+							const char *src = reinterpret_cast<const char *>(base) + voff + 1024u * p;
+							if (lane + kWave * p < P)
+								__builtin_amdgcn_global_load_lds((mf_gvoid *) src,
+								                                 (mf_lvoid *) (tile + n * S + 1024 * p), 16, 0, 0);
+						}
+					}
+					__builtin_amdgcn_s_waitcnt(0);          // vmcnt(0): the DMA has landed (single wave owns the tile)
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+					double e;
+					{
+						const double2 *t2 = reinterpret_cast<const double2 *>(tile + lane * S);
+						double dot = 0.0;
+#pragma unroll
+						for (int q = 0; q < P; ++q) {
+							const double2 t = t2[q];
+							const double2 x = xs[q];
+							dot = dot + x.x * t.x;
+							dot = dot + x.y * t.y;
+						}
+						e = a.c2 * (my_val - dot);
+					}
+					// scale in place: p_n[k] = e_n * y_n[k]
+					char *tb = tile + voff;
+					for (int n = 0; n < cnt; ++n) {
+						const double en = readlane_f64(e, n);
+#pragma unroll
+						for (int p = 0; p < NP; ++p)
+							if (lane + kWave * p < P) {
+								double2 *slot = reinterpret_cast<double2 *>(tb + n * S + 1024 * p);
+								double2 t = *slot;
+								t.x = en * t.x;
+								t.y = en * t.y;
+								*slot = t;
+							}
+					}
+				}
+			} else if (round > 0) {
+				// ---- accumulator: the tiles of round-1, producers in order, entries in order
+				const int base_c = beg + (round - 1) * per_round;
+				for (int pw = 0; pw < kCoopProducers; ++pw) {
+					const int cnt = max(0, min(nch, end - (base_c + pw * nch)));
+					const char *tb = tiles + (((round - 1) & 1) * kCoopProducers + pw) * tile_bytes + voff;
+					int n = 0;
+					for (; n + 8 <= cnt; n += 8) {
+						double2 t[8][NP];
+#pragma unroll
+						for (int u = 0; u < 8; ++u)
+#pragma unroll
+							for (int p = 0; p < NP; ++p)
+								t[u][p] = (lane + kWave * p < P)
+								              ? *reinterpret_cast<const double2 *>(tb + (n + u) * S + 1024 * p)
+								              : make_double2(0.0, 0.0);
+#pragma unroll
+						for (int u = 0; u < 8; ++u)
+#pragma unroll
+							for (int p = 0; p < NP; ++p) {
+								acc[p].x = acc[p].x + t[u][p].x;
+								acc[p].y = acc[p].y + t[u][p].y;
+							}
+					}
+					for (; n < cnt; ++n)
+#pragma unroll
+						for (int p = 0; p < NP; ++p)
+							if (lane + kWave * p < P) {
+								const double2 t = *reinterpret_cast<const double2 *>(tb + n * S + 1024 * p);
+								acc[p].x = acc[p].x + t.x;
+								acc[p].y = acc[p].y + t.y;
+							}
+				}
+			}
+			__syncthreads();
+		}
+		if (wave == 0) {
+			double2 *__restrict__ out2 = reinterpret_cast<double2 *>(a.X_new + (size_t) r * K);
+#pragma unroll
+			for (int p = 0; p < NP; ++p) {
+				const int q = lane + kWave * p;
+				if (q < P) out2[q] = acc[p];
+			}
+		}
+		__syncthreads();   // xs is rewritten for the next row
+	}
+}
+
 // In-process all-reduce of the item factor over peer-mapped buffers (the MPI_Iallreduce of
 // matFact-mpi.c:208 for the single-process multi-GPU path).  Shard g owns slice g of the buffer: it reads
 // that slice from every shard's buffer (xGMI peer loads), sums in shard order 0..N-1 -- a fixed order, so the

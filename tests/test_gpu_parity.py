@@ -376,3 +376,22 @@ def test_single_process_multi_shard_run(capi, orc, tmp_path):
     with pytest.raises(capi.HipBackendError) as e:
         capi.backend_run_multi(_inst(capi, d), L, R, [0, 7])
     assert e.value.status == capi.MF_ERR_NO_DEVICE
+
+
+@pytest.mark.parametrize("k", [10, 20, 30, 50])
+def test_row_cooperative_sweep_bit_exact(capi, orc, k, monkeypatch):
+    """Few rows, some of them long (>= 128 entries): the 8-wave row-cooperative kernel (producers gather and
+    scale, one accumulator wave adds in order) must reproduce the serial sums bit for bit, for every tile size."""
+    d = random_instance(500 + k, 150, 700, k, density=0.45, iters=3, alpha=2e-4, empty_rows=(5,), float_ratings=True)
+    Lo, Ro, bo = _oracle_run(orc, d)
+    for nch in (None, "5", "32"):
+        if nch:
+            monkeypatch.setenv("MF_SWEEP_NCH", nch)
+        plan = capi.Plan(150, 700, k, d["alpha"], d["row"], d["col"], d["val"])
+        assert "coop_nch=" in plan.describe() and not plan.describe().endswith("coop_nch=0")
+        L, R = capi.init_factors(150, 700, k)
+        plan.upload(L, R)
+        plan.iterate(3)
+        Lg, Rg = plan.download()
+        plan.close()
+        assert np.array_equal(Lg, Lo) and np.array_equal(Rg, Ro), (k, nch)
