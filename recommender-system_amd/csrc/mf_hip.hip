@@ -1,7 +1,11 @@
 // mf_hip.hip -- C ABI (include/matfact_hip.h) of the MI355X backend: plan management, CSR/CSC build,
 // kernel dispatch.  HIP only -- there is no CPU compute path in this library.
+#include <cstring>
+
 #include "../../include/matfact_hip.h"
 #include "mf_kernels.hip.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
 #include <cstdio>
@@ -218,6 +222,171 @@ void bucket(int64_t nnz, int nkeys, const int32_t *key, int32_t key_off, const i
 	}
 }
 
+
+// ---- device-side CSR / CSC build: the entries are uploaded once in file order; a STABLE radix
+// sort of a permutation by row (CSR) or by column (CSC) keeps the file order inside every row and column,
+// which is what makes the sweeps reproduce the serial summation order.
+__global__ void __launch_bounds__(256) prep_keys_kernel(const int *__restrict__ row, const int *__restrict__ col,
+                                                        int64_t nnz, int u0, int uc, int items,
+                                                        unsigned *__restrict__ rkey, unsigned *__restrict__ perm,
+                                                        int *__restrict__ flags)
+{
+	const int64_t n = (int64_t) blockIdx.x * 256 + threadIdx.x;
+	if (n >= nnz) return;
+	const int r = row[n] - u0, c = col[n];
+	if (r < 0 || r >= uc || c < 0 || c >= items) atomicOr(&flags[0], 1);         // out of range
+	if (n > 0 && row[n - 1] > row[n]) atomicOr(&flags[1], 1);                      // not row-sorted
+	rkey[n] = (unsigned) r;
+	perm[n] = (unsigned) n;
+}
+
+__global__ void __launch_bounds__(256) gather_kernel(const unsigned *__restrict__ perm, int64_t nnz,
+                                                     const int *__restrict__ other, int other_off,
+                                                     const double *__restrict__ val, int *__restrict__ idx_out,
+                                                     double *__restrict__ val_out)
+{
+	const int64_t n = (int64_t) blockIdx.x * 256 + threadIdx.x;
+	if (n >= nnz) return;
+	const unsigned s = perm[n];
+	idx_out[n] = other[s] - other_off;
+	val_out[n] = val[s];
+}
+
+// ptr[k] = first position whose (sorted) key is >= k, k = 0..nkeys
+__global__ void __launch_bounds__(256) ptr_kernel(const unsigned *__restrict__ sorted, int64_t nnz, int nkeys,
+                                                  int *__restrict__ ptr)
+{
+	const int k = blockIdx.x * 256 + threadIdx.x;
+	if (k > nkeys) return;
+	int64_t lo = 0, hi = nnz;
+	while (lo < hi) {
+		const int64_t mid = (lo + hi) >> 1;
+		if (sorted[mid] < (unsigned) k) lo = mid + 1; else hi = mid;
+	}
+	ptr[k] = (int) lo;
+}
+
+__global__ void __launch_bounds__(256) copy_keys_kernel(const int *__restrict__ src, int64_t nnz,
+                                                        unsigned *__restrict__ key, unsigned *__restrict__ perm)
+{
+	const int64_t n = (int64_t) blockIdx.x * 256 + threadIdx.x;
+	if (n >= nnz) return;
+	key[n] = (unsigned) src[n];
+	perm[n] = (unsigned) n;
+}
+
+int bits_for(int nkeys)
+{
+	int b = 1;
+	while (b < 32 && (1ll << b) < (long long) nkeys) ++b;
+	return b;
+}
+
+struct DevTmp {   // frees its buffers on scope exit
+	std::vector<void *> bufs;
+	~DevTmp() { for (void *b : bufs) (void) hipFree(b); }
+	template <typename T> int get(T **out, size_t count)
+	{
+		const int rc = dev_alloc(out, count);
+		if (rc == MF_OK) bufs.push_back(*out);
+		return rc;
+	}
+};
+
+// Builds csr_* and csc_* of plan p from host SoA entries.  Returns MF_ERR_ARGUMENT for out-of-range indices.
+int build_on_device(mf_plan *p, const mf_shard *s, std::vector<int> &csr_ptr_host, std::vector<int> &csc_ptr_host)
+{
+	const int64_t nnz = s->nnz;
+	const size_t nz = (size_t) nnz;
+	hipStream_t st = p->stream;
+	MF_HIP(dev_alloc(&p->csr_ptr, (size_t) p->uc + 1) == MF_OK ? hipSuccess : hipErrorOutOfMemory);
+	MF_HIP(dev_alloc(&p->csc_ptr, (size_t) p->items + 1) == MF_OK ? hipSuccess : hipErrorOutOfMemory);
+	MF_HIP(dev_alloc(&p->csr_idx, nz + 64) == MF_OK ? hipSuccess : hipErrorOutOfMemory);
+	MF_HIP(dev_alloc(&p->csr_val, nz + 64) == MF_OK ? hipSuccess : hipErrorOutOfMemory);
+	MF_HIP(dev_alloc(&p->csc_idx, nz + 64) == MF_OK ? hipSuccess : hipErrorOutOfMemory);
+	MF_HIP(dev_alloc(&p->csc_val, nz + 64) == MF_OK ? hipSuccess : hipErrorOutOfMemory);
+	csr_ptr_host.assign((size_t) p->uc + 1, 0);
+	csc_ptr_host.assign((size_t) p->items + 1, 0);
+	if (nnz == 0) {
+		MF_HIP(hipMemsetAsync(p->csr_ptr, 0, ((size_t) p->uc + 1) * sizeof(int), st));
+		MF_HIP(hipMemsetAsync(p->csc_ptr, 0, ((size_t) p->items + 1) * sizeof(int), st));
+		MF_HIP(hipStreamSynchronize(st));
+		return MF_OK;
+	}
+	DevTmp tmp;
+	int *d_row = nullptr, *d_col = nullptr, *d_flags = nullptr;
+	unsigned *key_in = nullptr, *key_out = nullptr, *perm_in = nullptr, *perm_out = nullptr;
+	int rc;
+	if ((rc = tmp.get(&d_row, nz)) != MF_OK || (rc = tmp.get(&d_col, nz)) != MF_OK ||
+	    (rc = tmp.get(&key_in, nz)) != MF_OK || (rc = tmp.get(&key_out, nz)) != MF_OK ||
+	    (rc = tmp.get(&perm_in, nz)) != MF_OK || (rc = tmp.get(&perm_out, nz)) != MF_OK ||
+	    (rc = tmp.get(&d_flags, 2)) != MF_OK)
+		return rc;
+	// the values land directly in csr_val when the input is row-sorted (the usual case); otherwise csc_val is
+	// used as the staging copy of the file-order values and overwritten last
+	double *d_val = p->csc_val;
+	MF_HIP(hipMemcpyAsync(d_row, s->row, nz * sizeof(int), hipMemcpyHostToDevice, st));
+	MF_HIP(hipMemcpyAsync(d_col, s->col, nz * sizeof(int), hipMemcpyHostToDevice, st));
+	MF_HIP(hipMemcpyAsync(p->csr_val, s->val, nz * sizeof(double), hipMemcpyHostToDevice, st));
+	MF_HIP(hipMemsetAsync(d_flags, 0, 2 * sizeof(int), st));
+	const unsigned grid = (unsigned) ((nnz + 255) / 256);
+	hipLaunchKernelGGL(prep_keys_kernel, dim3(grid), dim3(256), 0, st, d_row, d_col, nnz, p->u0, p->uc, p->items,
+	                   key_in, perm_in, d_flags);
+	int flags[2] = {0, 0};
+	MF_HIP(hipMemcpyAsync(flags, d_flags, sizeof flags, hipMemcpyDeviceToHost, st));
+	MF_HIP(hipStreamSynchronize(st));
+	if (flags[0]) return MF_ERR_ARGUMENT;
+	const bool row_sorted = flags[1] == 0;
+
+	size_t temp_bytes = 0, need = 0;
+	MF_HIP(rocprim::radix_sort_pairs(nullptr, need, key_in, key_out, perm_in, perm_out, nz, 0, bits_for(p->uc), st));
+	temp_bytes = need;
+	MF_HIP(rocprim::radix_sort_pairs(nullptr, need, key_in, key_out, perm_in, perm_out, nz, 0, bits_for(p->items), st));
+	temp_bytes = std::max(temp_bytes, need);
+	void *d_temp = nullptr;
+	if ((rc = tmp.get((char **) &d_temp, temp_bytes)) != MF_OK) return rc;
+
+	const double *vals_file_order = p->csr_val;   // file-order values currently live here
+	if (row_sorted) {
+		// CSR == file order: idx = col, val = val (already in place), ptr from the row keys
+		MF_HIP(hipMemcpyAsync(p->csr_idx, d_col, nz * sizeof(int), hipMemcpyDeviceToDevice, st));
+		hipLaunchKernelGGL(ptr_kernel, dim3((unsigned) ((p->uc + 256) / 256)), dim3(256), 0, st, key_in, nnz, p->uc,
+		                   p->csr_ptr);
+	} else {
+		// keep a file-order copy of the values, then permute into csr_val
+		MF_HIP(hipMemcpyAsync(d_val, p->csr_val, nz * sizeof(double), hipMemcpyDeviceToDevice, st));
+		vals_file_order = d_val;
+		MF_HIP(rocprim::radix_sort_pairs(d_temp, temp_bytes, key_in, key_out, perm_in, perm_out, nz, 0,
+		                                 bits_for(p->uc), st));
+		hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(256), 0, st, perm_out, nnz, d_col, 0, vals_file_order,
+		                   p->csr_idx, p->csr_val);
+		hipLaunchKernelGGL(ptr_kernel, dim3((unsigned) ((p->uc + 256) / 256)), dim3(256), 0, st, key_out, nnz, p->uc,
+		                   p->csr_ptr);
+	}
+	// CSC: stable sort of the file order by column
+	hipLaunchKernelGGL(copy_keys_kernel, dim3(grid), dim3(256), 0, st, d_col, nnz, key_in, perm_in);
+	MF_HIP(rocprim::radix_sort_pairs(d_temp, temp_bytes, key_in, key_out, perm_in, perm_out, nz, 0,
+	                                 bits_for(p->items), st));
+	if (row_sorted) {
+		hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(256), 0, st, perm_out, nnz, d_row, p->u0, vals_file_order,
+		                   p->csc_idx, p->csc_val);
+	} else {
+		// vals_file_order aliases csc_val: gather into a temporary, then copy
+		double *d_val2 = nullptr;
+		if ((rc = tmp.get(&d_val2, nz)) != MF_OK) return rc;
+		hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(256), 0, st, perm_out, nnz, d_row, p->u0, vals_file_order,
+		                   p->csc_idx, d_val2);
+		MF_HIP(hipMemcpyAsync(p->csc_val, d_val2, nz * sizeof(double), hipMemcpyDeviceToDevice, st));
+	}
+	hipLaunchKernelGGL(ptr_kernel, dim3((unsigned) ((p->items + 256) / 256)), dim3(256), 0, st, key_out, nnz, p->items,
+	                   p->csc_ptr);
+	MF_HIP(hipGetLastError());
+	MF_HIP(hipMemcpyAsync(csr_ptr_host.data(), p->csr_ptr, ((size_t) p->uc + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+	MF_HIP(hipMemcpyAsync(csc_ptr_host.data(), p->csc_ptr, ((size_t) p->items + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+	MF_HIP(hipStreamSynchronize(st));
+	return MF_OK;
+}
+
 int launch_sweep(mf_plan *p, int kind, int seed)
 {
 	mf::SweepArgs a;
@@ -325,11 +494,6 @@ int mf_plan_create(mf_plan **out, const mf_shard *s)
 	    s->user_count < 0 || (int64_t) s->user_begin + s->user_count > s->users_total ||
 	    s->nnz > INT32_MAX - 64 || (s->nnz > 0 && (!s->row || !s->col || !s->val)))
 		return MF_ERR_ARGUMENT;
-	for (int64_t n = 0; n < s->nnz; ++n)
-		if (s->row[n] < s->user_begin || s->row[n] >= s->user_begin + s->user_count || s->col[n] < 0 ||
-		    s->col[n] >= s->items)
-			return MF_ERR_ARGUMENT;
-
 	const int ndev = mf_backend_device_count();
 	if (ndev <= 0 || s->device < 0 || s->device >= ndev) return MF_ERR_NO_DEVICE;
 	MF_HIP(hipSetDevice(s->device));
@@ -356,13 +520,6 @@ int mf_plan_create(mf_plan **out, const mf_shard *s)
 	if (hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(MF_ERR_HIP);
 	p->stream = p->own_stream;
 
-	std::vector<int> ptr, idx;
-	std::vector<double> val;
-	try {
-		bucket(s->nnz, p->uc, s->row, p->u0, s->col, 0, s->val, ptr, idx, val);
-	} catch (const std::bad_alloc &) {
-		return fail(MF_ERR_NO_MEMORY);
-	}
 #define MF_TRY(x)                       \
 	do {                                \
 		int _rc = (x);                  \
@@ -376,29 +533,48 @@ int mf_plan_create(mf_plan **out, const mf_shard *s)
 			return fail(_e == hipErrorOutOfMemory ? MF_ERR_NO_MEMORY : MF_ERR_HIP);   \
 		}                                                                             \
 	} while (0)
-	for (int u = 0; u < p->uc; ++u) p->max_row_len[1] = std::max(p->max_row_len[1], ptr[(size_t) u + 1] - ptr[u]);
-	const size_t nz = (size_t) s->nnz;
-	MF_TRY(dev_alloc(&p->csr_ptr, (size_t) p->uc + 1));
-	MF_TRY(dev_alloc(&p->csr_idx, nz + 64));
-	MF_TRY(dev_alloc(&p->csr_val, nz + 64));
-	MF_TRY_HIP(hipMemcpy(p->csr_ptr, ptr.data(), ((size_t) p->uc + 1) * sizeof(int), hipMemcpyHostToDevice));
-	if (nz) {
-		MF_TRY_HIP(hipMemcpy(p->csr_idx, idx.data(), nz * sizeof(int), hipMemcpyHostToDevice));
-		MF_TRY_HIP(hipMemcpy(p->csr_val, val.data(), nz * sizeof(double), hipMemcpyHostToDevice));
-	}
-	try {
-		bucket(s->nnz, p->items, s->col, 0, s->row, p->u0, s->val, ptr, idx, val);
-	} catch (const std::bad_alloc &) {
-		return fail(MF_ERR_NO_MEMORY);
-	}
-	for (int j = 0; j < p->items; ++j) p->max_row_len[0] = std::max(p->max_row_len[0], ptr[(size_t) j + 1] - ptr[j]);
-	MF_TRY(dev_alloc(&p->csc_ptr, (size_t) p->items + 1));
-	MF_TRY(dev_alloc(&p->csc_idx, nz + 64));
-	MF_TRY(dev_alloc(&p->csc_val, nz + 64));
-	MF_TRY_HIP(hipMemcpy(p->csc_ptr, ptr.data(), ((size_t) p->items + 1) * sizeof(int), hipMemcpyHostToDevice));
-	if (nz) {
-		MF_TRY_HIP(hipMemcpy(p->csc_idx, idx.data(), nz * sizeof(int), hipMemcpyHostToDevice));
-		MF_TRY_HIP(hipMemcpy(p->csc_val, val.data(), nz * sizeof(double), hipMemcpyHostToDevice));
+	{
+		const char *where = getenv("MF_BUILD");   // "device" (default) | "host": CSR/CSC bucketing on the CPU
+		std::vector<int> rptr, cptr;
+		if (where && strcmp(where, "host") == 0) {
+			for (int64_t n = 0; n < s->nnz; ++n)
+				if (s->row[n] < s->user_begin || s->row[n] >= s->user_begin + s->user_count || s->col[n] < 0 ||
+				    s->col[n] >= s->items)
+					return fail(MF_ERR_ARGUMENT);
+			std::vector<int> idx;
+			std::vector<double> val;
+			const size_t nz = (size_t) s->nnz;
+			try {
+				bucket(s->nnz, p->uc, s->row, p->u0, s->col, 0, s->val, rptr, idx, val);
+			} catch (const std::bad_alloc &) {
+				return fail(MF_ERR_NO_MEMORY);
+			}
+			MF_TRY(dev_alloc(&p->csr_ptr, (size_t) p->uc + 1));
+			MF_TRY(dev_alloc(&p->csr_idx, nz + 64));
+			MF_TRY(dev_alloc(&p->csr_val, nz + 64));
+			MF_TRY_HIP(hipMemcpy(p->csr_ptr, rptr.data(), ((size_t) p->uc + 1) * sizeof(int), hipMemcpyHostToDevice));
+			if (nz) {
+				MF_TRY_HIP(hipMemcpy(p->csr_idx, idx.data(), nz * sizeof(int), hipMemcpyHostToDevice));
+				MF_TRY_HIP(hipMemcpy(p->csr_val, val.data(), nz * sizeof(double), hipMemcpyHostToDevice));
+			}
+			try {
+				bucket(s->nnz, p->items, s->col, 0, s->row, p->u0, s->val, cptr, idx, val);
+			} catch (const std::bad_alloc &) {
+				return fail(MF_ERR_NO_MEMORY);
+			}
+			MF_TRY(dev_alloc(&p->csc_ptr, (size_t) p->items + 1));
+			MF_TRY(dev_alloc(&p->csc_idx, nz + 64));
+			MF_TRY(dev_alloc(&p->csc_val, nz + 64));
+			MF_TRY_HIP(hipMemcpy(p->csc_ptr, cptr.data(), ((size_t) p->items + 1) * sizeof(int), hipMemcpyHostToDevice));
+			if (nz) {
+				MF_TRY_HIP(hipMemcpy(p->csc_idx, idx.data(), nz * sizeof(int), hipMemcpyHostToDevice));
+				MF_TRY_HIP(hipMemcpy(p->csc_val, val.data(), nz * sizeof(double), hipMemcpyHostToDevice));
+			}
+		} else {
+			MF_TRY(build_on_device(p, s, rptr, cptr));
+		}
+		for (int u = 0; u < p->uc; ++u) p->max_row_len[1] = std::max(p->max_row_len[1], rptr[(size_t) u + 1] - rptr[u]);
+		for (int j = 0; j < p->items; ++j) p->max_row_len[0] = std::max(p->max_row_len[0], cptr[(size_t) j + 1] - cptr[j]);
 	}
 
 	const size_t nl = (size_t) p->uc * p->K, nr = (size_t) p->items * p->K;
