@@ -395,3 +395,15 @@ def test_row_cooperative_sweep_bit_exact(capi, orc, k, monkeypatch):
         Lg, Rg = plan.download()
         plan.close()
         assert np.array_equal(Lg, Lo) and np.array_equal(Rg, Ro), (k, nch)
+
+
+def test_multi_shard_item_heavy_instance_cuts_the_items(capi, orc):
+    """items > users: the sharded run cuts the ITEMS (roles of L and R exchanged, mpiutil.c:54-88 /
+    matFact-omp.c:44) -- results still those of the serial program (R rows exact, L summed across shards)."""
+    d = random_instance(17, 24, 900, 20, density=0.3, iters=10, alpha=0.001, empty_rows=(3,))
+    Lo, Ro, bo = _oracle_run(orc, d)
+    for nd in (2, 4):
+        L, R = capi.init_factors(24, 900, 20)
+        best = capi.backend_run_multi(_inst(capi, d), L, R, [0] * nd)
+        assert np.allclose(L, Lo, rtol=1e-9, atol=1e-13) and np.allclose(R, Ro, rtol=1e-9, atol=1e-13), nd
+        assert np.array_equal(best, bo), nd
