@@ -184,13 +184,20 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 			acc[p] = a.seed ? v : make_double2(0.0, 0.0);
 		}
 
+		// (idx, val) of a chunk are loaded one chunk ahead, so the gather of chunk c never waits on them
+		int nx_idx = 0;
+		double nx_val = 0.0;
+		if (beg + lane < min(end, beg + nch)) {
+			nx_idx = a.idx[beg + lane];
+			nx_val = a.val[beg + lane];
+		}
 		for (int c = beg; c < end; c += nch) {
 			const int cnt = min(nch, end - c);
-			int my_idx = 0;
-			double my_val = 0.0;
-			if (lane < cnt) {
-				my_idx = a.idx[c + lane];
-				my_val = a.val[c + lane];
+			const int my_idx = nx_idx;
+			const double my_val = nx_val;
+			if (c + nch + lane < min(end, c + 2 * nch)) {
+				nx_idx = a.idx[c + nch + lane];
+				nx_val = a.val[c + nch + lane];
 			}
 			// ---- stage: one DMA per gathered row and pass
 			for (int n = 0; n < cnt; ++n) {
