@@ -49,8 +49,15 @@ constexpr SweepVariant variant()
 template <int KT>
 constexpr SweepVariant dma_variant()
 {
-	return SweepVariant{mf::sweep_dma_kernel<KT>, KT, 0, 1, mf::DmaGeom<KT>::kStride, mf::DmaGeom<KT>::kXsBytes,
-	                    mf::sweep_coop_kernel<KT>};
+	return SweepVariant{mf::sweep_dma_kernel<KT, mf::DmaGeom<KT>::kPasses>, KT, 0, 1, mf::DmaGeom<KT>::kStride,
+	                    mf::DmaGeom<KT>::kXsBytes, mf::sweep_coop_kernel<KT>};
+}
+
+// run-time even K <= 128 * NPASS through the LDS-DMA kernel (row_bytes / xs_bytes filled in per plan)
+template <int NPASS>
+constexpr SweepVariant dma_generic_variant()
+{
+	return SweepVariant{mf::sweep_dma_kernel<0, NPASS>, 0, NPASS, 1, 0, 0, nullptr};
 }
 
 // K-specialised instances for the K of the bundled samples and of the BASELINE configs, then generic ones.
@@ -62,6 +69,9 @@ const SweepVariant kSpecialised[] = {
 const SweepVariant kDma[] = {
     dma_variant<10>(), dma_variant<20>(), dma_variant<30>(), dma_variant<50>(),
     dma_variant<100>(), dma_variant<128>(), dma_variant<256>(),
+};
+const SweepVariant kDmaGeneric[] = {
+    dma_generic_variant<1>(), dma_generic_variant<2>(), dma_generic_variant<4>(), dma_generic_variant<8>(),
 };
 const SweepVariant kGeneric[] = {
     variant<0, 1>(), variant<0, 2>(), variant<0, 4>(), variant<0, 8>(),
@@ -132,6 +142,13 @@ int choose_sweep(mf_plan *p)
 	if (allow_dma)
 		for (const auto &v : kDma)
 			if (v.kt == K) p->sweep = v;
+	if (!p->sweep.fn && allow_dma && (K & 1) == 0)
+		for (const auto &v : kDmaGeneric)
+			if (K <= 128 * v.kpmax && !p->sweep.fn) {
+				p->sweep = v;
+				p->sweep.row_bytes = 16 * ((K / 2) | 1);
+				p->sweep.xs_bytes = ((K * 8 + 255) / 256) * 256;
+			}
 	if (!p->sweep.fn)
 		for (const auto &v : kSpecialised)
 			if (v.kt == K) p->sweep = v;
@@ -838,8 +855,9 @@ int mf_plan_describe(mf_plan *p, char *buf, int buflen)
 {
 	if (!p || !buf || buflen <= 0) return MF_ERR_ARGUMENT;
 	if (p->sweep.dma)
-		snprintf(buf, (size_t) buflen, "sweep_dma_kernel<KT=%d> K=%d nch=%d row_bytes=%d lds=%zu coop_nch=%d",
-		         p->sweep.kt, p->K, p->nch, p->sweep.row_bytes, p->lds_bytes, p->nch_coop);
+		snprintf(buf, (size_t) buflen, "sweep_dma_kernel<KT=%d,NPASS=%d> K=%d nch=%d row_bytes=%d lds=%zu coop_nch=%d",
+		         p->sweep.kt, p->sweep.kt ? (p->K / 2 + 63) / 64 : p->sweep.kpmax, p->K, p->nch, p->sweep.row_bytes,
+		         p->lds_bytes, p->nch_coop);
 	else
 		snprintf(buf, (size_t) buflen, "sweep_kernel<KT=%d,KPMAX=%d> K=%d nch=%d stride=%d lds=%zu",
 		         p->sweep.kt, p->sweep.kpmax, p->K, p->nch, p->stride, p->lds_bytes);

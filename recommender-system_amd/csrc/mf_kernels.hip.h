@@ -155,14 +155,20 @@ struct DmaGeom {
 	static constexpr int kXsBytes = ((KT * 8 + 255) / 256) * 256;
 };
 
-template <int KT>
+// KT > 0: K is a compile-time constant (phase A fully unrolled).  KT == 0: any even K up to 128*NPASS at run
+// time (phase A unrolled by four) -- same data movement, so an unusual K does not fall back to the
+// register-staged kernel.
+template <int KT, int NPASS>
 __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 {
-	using G = DmaGeom<KT>;
-	constexpr int K = KT, P = G::kPieces, NP = G::kPasses, S = G::kStride;
+	const int K = KT > 0 ? KT : a.K;
+	const int P = K >> 1;                                   // 16-B pieces per row
+	constexpr int NP = NPASS;                               // DMA instructions per row
+	const int S = 16 * (P | 1);                             // tile row stride, odd multiple of 16 B
+	const int xs_bytes = ((K * 8 + 255) / 256) * 256;
 	extern __shared__ __attribute__((aligned(16))) char lds[];
 	double2 *xs = reinterpret_cast<double2 *>(lds);
-	char *tile = lds + G::kXsBytes;
+	char *tile = lds + xs_bytes;
 	const int nch = a.nch;
 	const int lane = threadIdx.x;
 	const unsigned voff = (unsigned) lane * 16u;
@@ -218,12 +224,35 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 			{
 				const double2 *t2 = reinterpret_cast<const double2 *>(tile + lane * S);
 				double dot = 0.0;
+				if (KT > 0) {
 #pragma unroll
-				for (int q = 0; q < P; ++q) {
-					const double2 t = t2[q];
-					const double2 x = xs[q];
-					dot = dot + x.x * t.x;
-					dot = dot + x.y * t.y;
+					for (int q = 0; q < KT / 2; ++q) {
+						const double2 t = t2[q];
+						const double2 x = xs[q];
+						dot = dot + x.x * t.x;
+						dot = dot + x.y * t.y;
+					}
+				} else {
+					int q = 0;
+					for (; q + 4 <= P; q += 4) {
+						double2 t[4], x[4];
+#pragma unroll
+						for (int u = 0; u < 4; ++u) {
+							t[u] = t2[q + u];
+							x[u] = xs[q + u];
+						}
+#pragma unroll
+						for (int u = 0; u < 4; ++u) {
+							dot = dot + x[u].x * t[u].x;
+							dot = dot + x[u].y * t[u].y;
+						}
+					}
+					for (; q < P; ++q) {
+						const double2 t = t2[q];
+						const double2 x = xs[q];
+						dot = dot + x.x * t.x;
+						dot = dot + x.y * t.y;
+					}
 				}
 				e = a.c2 * (my_val - dot);
 			}
