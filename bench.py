@@ -41,6 +41,29 @@ def algorithmic_bytes(nnz, feats, rows_owned):
     return nnz * (8 + 8 * feats) + 16 * feats * rows_owned
 
 
+def skewed_instance(seed, users, items, target_nnz, lo=20):
+    """Power-law stand-in for MovieLens-like data: user activity ~ rank^-0.8 clipped to
+    [20, items/1.7], item popularity ~ rank^-0.9 (shuffled), distinct items per user by Gumbel top-k."""
+    rng = np.random.default_rng(seed)
+    act = (np.arange(users) + 1.0) ** -0.8
+    m = np.clip(np.round(act / act.sum() * target_nnz), lo, int(items / 1.7)).astype(np.int64)
+    m = m[rng.permutation(users)]
+    logw = -0.9 * np.log(np.arange(items) + 1.0)[rng.permutation(items)]
+    rows, cols = [], []
+    for start in range(0, users, 512):
+        blk = m[start:start + 512]
+        keys = logw[None, :] + rng.gumbel(size=(len(blk), items))
+        order = np.argsort(-keys, axis=1)
+        for i, mi in enumerate(blk):
+            c = np.sort(order[i, :mi])
+            cols.append(c)
+            rows.append(np.full(mi, start + i))
+    row = np.concatenate(rows).astype(np.int32)
+    col = np.concatenate(cols).astype(np.int32)
+    val = rng.integers(1, 6, row.shape[0]).astype(np.float64)
+    return row, col, val
+
+
 def cpu_baseline(cfg, capi, budget_s=12.0):
     """OpenMP port of matFact-omp.c (oracle/mf_oracle.c: orc_factorize_omp) on a bounded sample of the SAME
     workload: the first `sample_users` users (all items, same K), loop time only."""
@@ -91,6 +114,9 @@ def main():
     ap.add_argument("--partition", default="entries", choices=["entries", "rows"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo only to rehearse several ranks on ONE GPU")
+    ap.add_argument("--skew", action="store_true",
+                    help="power-law instance of the config's shape (row lengths and item popularity Zipf-like, as "
+                         "MovieLens is) instead of the uniform generator; single rank, small configs only")
     ap.add_argument("--recommend", action="store_true",
                     help="also time the fused L*R^T masked top-1 step (reported beside, never inside, `value`)")
     ap.add_argument("--check", action="store_true",
@@ -136,6 +162,11 @@ def main():
     begin = capi.partition_users(U, world, ptr if args.partition == "entries" else None)
     u0, uc = int(begin[rank]), int(begin[rank + 1] - begin[rank])
     row, col, val = capi.synth_block(cfg["seed"], U, I, cfg["min_row"], cfg["max_row"], u0, uc)
+    if args.skew:
+        if world != 1 or U * I > 5e8:
+            raise SystemExit("--skew: single rank and users*items <= 5e8 only")
+        row, col, val = skewed_instance(cfg["seed"], U, I, total_nnz)
+        total_nnz = int(row.shape[0])
     nnz_loc = int(row.shape[0])
     Lb, R0 = capi.init_factors_block(U, I, K, u0, uc)     # the reference's init rule (mat2d.c:61-72)
     r_bufs = [torch.empty(I, K, dtype=torch.float64, device=dev) for _ in range(2)]
@@ -203,8 +234,9 @@ def main():
         "metric": "nnz_updates_per_sec", "value": total_nnz * args.steps / elapsed, "unit": "nnz-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%s: synthetic %dx%d, K=%d, nnz=%d, alpha=%g, rows %d..%d entries, uniform columns"
-                               % (args.config, U, I, K, total_nnz, cfg["alpha"], cfg["min_row"], cfg["max_row"]),
+        "config": {"workload": ("%s: synthetic %dx%d, K=%d, nnz=%d, alpha=%g, " % (args.config, U, I, K, total_nnz, cfg["alpha"]))
+                               + ("power-law rows and item popularity" if args.skew else
+                                  "rows %d..%d entries, uniform columns" % (cfg["min_row"], cfg["max_row"])),
                    "users": U, "items": I, "K": K, "nnz": total_nnz,
                    "parallelism": "1 GPU" if world == 1 else "row-shard x%d (by %s) + RCCL all-reduce(R) per iteration"
                                   % (world, args.partition)},

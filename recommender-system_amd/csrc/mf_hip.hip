@@ -121,9 +121,19 @@ struct mf_plan {
 	size_t lds_bytes = 0;
 	int nch_few = 0;            // chunk size when a sweep has too few rows to fill the chip (see choose_sweep)
 	size_t lds_bytes_few = 0;
-	int nch_coop = 0;           // chunk size of the row-cooperative form (0: not available)
-	size_t lds_bytes_coop = 0;
 	int max_row_len[2] = {0, 0}; // longest column (item sweep) / longest user row (user sweep)
+	// skew-aware split of a sweep with many rows: rows whose serial walk would dominate the launch go to the
+	// row-cooperative kernel on a side stream, the others stay on the single-wave kernel
+	int *long_rows[2] = {nullptr, nullptr}, *short_rows[2] = {nullptr, nullptr};
+	int n_long[2] = {0, 0}, n_short[2] = {0, 0};
+	int nch_long = 0;
+	size_t lds_bytes_long = 0;
+	// tiny sweeps (a few us of data): ONE cooperative launch over all rows; a fork/join costs more than it saves
+	int nch_coop = 0;
+	size_t lds_bytes_coop = 0;
+	bool coop_all[2] = {false, false};
+	hipStream_t side_stream = nullptr;
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
 	bool timing = false;
 	std::vector<TimedLaunch> timed;
@@ -190,26 +200,6 @@ int choose_sweep(mf_plan *p)
 	p->lds_bytes_few = head + (size_t) few * row_bytes;
 	MF_HIP(hipFuncSetAttribute((const void *) p->sweep.fn, hipFuncAttributeMaxDynamicSharedMemorySize,
 	                           (int) std::max(p->lds_bytes, p->lds_bytes_few)));
-	// row-cooperative form: 2 buffers x 7 producer tiles in ~110 KB, 4..32 entries per tile
-	p->nch_coop = 0;
-	const char *coop_env = getenv("MF_SWEEP_COOP");   // "0" disables
-	if (p->sweep.coop && !(coop_env && coop_env[0] == '0')) {
-		// ~48 KB of tiles per workgroup keeps 3 rows resident per CU (ML100k: 24-entry tiles 0.38 s, 32-entry
-		// tiles -- one workgroup per CU -- 0.55 s); below 8 entries per tile phase A's K steps dominate, so large
-		// K keeps the single-wave form with 64-entry chunks
-		const size_t per_entry = 2 * (size_t) mf::kCoopProducers * row_bytes;
-		int nc = (int) std::min<size_t>(32, (48 * 1024) / per_entry);
-		if (const char *env = getenv("MF_SWEEP_NCH")) {
-			const int v = atoi(env);
-			if (v >= 1 && v <= 64 && head + (size_t) v * per_entry <= kLdsPerCu) nc = v;
-		}
-		if (nc >= 8 || getenv("MF_SWEEP_NCH")) {
-			p->nch_coop = std::max(nc, 1);
-			p->lds_bytes_coop = head + (size_t) p->nch_coop * per_entry;
-			MF_HIP(hipFuncSetAttribute((const void *) p->sweep.coop, hipFuncAttributeMaxDynamicSharedMemorySize,
-			                           (int) p->lds_bytes_coop));
-		}
-	}
 	return MF_OK;
 }
 
@@ -430,10 +420,10 @@ int launch_sweep(mf_plan *p, int kind, int seed)
 		a.Y_old = p->Rbuf[p->cur];
 		a.X_new = p->Lbuf[nxt];
 	}
+	a.rowlist = nullptr;
 	if (a.nrows <= 0) return MF_OK;
 	const bool few_rows = a.nrows < 4096;
-	// cooperative form only where a long row's serial walk is the launch time
-	const bool coop = few_rows && p->nch_coop > 0 && p->max_row_len[kind] >= 128;
+	const bool coop = p->coop_all[kind];
 	if (few_rows) a.nch = coop ? p->nch_coop : p->nch_few;
 	const size_t lds = coop ? p->lds_bytes_coop : (few_rows ? p->lds_bytes_few : p->lds_bytes);
 	const SweepFn fn = coop ? p->sweep.coop : p->sweep.fn;
@@ -447,7 +437,27 @@ int launch_sweep(mf_plan *p, int kind, int seed)
 		MF_HIP(hipEventRecord(t.t0, p->stream));
 	}
 	void *args[] = {&a};
-	MF_HIP(hipLaunchKernel((const void *) fn, dim3(grid), dim3(block), args, lds, p->stream));
+	if (p->n_long[kind] > 0) {
+		// long rows: cooperative kernel on the side stream, concurrently with the short rows on the main stream
+		mf::SweepArgs b = a;
+		b.nrows = p->n_long[kind];
+		b.rowlist = p->long_rows[kind];
+		b.nch = p->nch_long;
+		void *bargs[] = {&b};
+		MF_HIP(hipEventRecord(p->ev_fork, p->stream));
+		MF_HIP(hipStreamWaitEvent(p->side_stream, p->ev_fork, 0));
+		MF_HIP(hipLaunchKernel((const void *) p->sweep.coop, dim3(b.nrows), dim3(mf::kCoopWaves * mf::kWave), bargs,
+		                       p->lds_bytes_long, p->side_stream));
+		MF_HIP(hipEventRecord(p->ev_join, p->side_stream));
+		a.nrows = p->n_short[kind];
+		a.rowlist = p->short_rows[kind];
+		if (a.nrows > 0)
+			MF_HIP(hipLaunchKernel((const void *) fn, dim3(std::min(a.nrows, 1 << 20)), dim3(block), args, lds,
+			                       p->stream));
+		MF_HIP(hipStreamWaitEvent(p->stream, p->ev_join, 0));
+	} else {
+		MF_HIP(hipLaunchKernel((const void *) fn, dim3(grid), dim3(block), args, lds, p->stream));
+	}
 	if (p->timing) {
 		MF_HIP(hipEventRecord(t.t1, p->stream));
 		p->timed.push_back(t);
@@ -592,6 +602,59 @@ int mf_plan_create(mf_plan **out, const mf_shard *s)
 		}
 		for (int u = 0; u < p->uc; ++u) p->max_row_len[1] = std::max(p->max_row_len[1], rptr[(size_t) u + 1] - rptr[u]);
 		for (int j = 0; j < p->items; ++j) p->max_row_len[0] = std::max(p->max_row_len[0], cptr[(size_t) j + 1] - cptr[j]);
+		// ---- long / short row lists.  A row is "long" when its serial walk (~0.075 us per entry at 16-entry
+		// chunks) would exceed roughly a quarter of the bandwidth time of the whole sweep (nnz * 8K bytes at
+		// ~7 TB/s): len > 4e-6 * nnz * K, and never below 128 entries.  cfg4 has none; a power-law instance a few.
+		const char *skew_env = getenv("MF_SWEEP_SKEW");   // "0" disables the split
+		if (p->sweep.coop && !(skew_env && skew_env[0] == '0')) {
+			const size_t per_entry = 2 * (size_t) mf::kCoopProducers * (size_t) p->sweep.row_bytes;
+			const size_t head = (size_t) p->sweep.xs_bytes;
+			int nl = (int) std::min<size_t>(32, (kLdsPerCu - 4096 - head) / per_entry);
+			if (const char *env = getenv("MF_SWEEP_NCH")) {
+				const int v = atoi(env);
+				if (v >= 1 && v <= 64 && head + (size_t) v * per_entry <= kLdsPerCu) nl = v;
+			}
+			double thr = 4e-6 * (double) p->nnz * (double) p->K;
+			if (const char *t = getenv("MF_SWEEP_LONG")) thr = atof(t);
+			const int t_long = std::max(128, (int) std::min(thr, 2e9));
+			// estimated bandwidth time of one sweep; below ~50 us the two-stream fork/join (tens of us on the 6000
+			// launches of ML100k) costs more than the split saves: use one cooperative launch for all rows there
+			const double est_us = (double) p->nnz * 8.0 * p->K / 6e12 * 1e6;
+			const int nc = (int) std::min<size_t>(32, (48 * 1024) / per_entry);
+			for (int kind = 0; kind < 2 && nl >= 4; ++kind) {
+				const std::vector<int> &pt = kind == 0 ? cptr : rptr;
+				const int nrows = kind == 0 ? p->items : p->uc;
+				if (p->max_row_len[kind] < t_long) continue;
+				if (est_us < 50.0 && nrows < 4096 && !getenv("MF_SWEEP_LONG")) {
+					if (nc >= 8 || getenv("MF_SWEEP_NCH")) {
+						p->coop_all[kind] = true;
+						p->nch_coop = getenv("MF_SWEEP_NCH") ? nl : nc;
+						p->lds_bytes_coop = head + (size_t) p->nch_coop * per_entry;
+					}
+					continue;
+				}
+				std::vector<int> lg, sh;
+				for (int r = 0; r < nrows; ++r) (pt[(size_t) r + 1] - pt[r] >= t_long ? lg : sh).push_back(r);
+				MF_TRY(dev_alloc(&p->long_rows[kind], lg.size()));
+				MF_TRY(dev_alloc(&p->short_rows[kind], sh.size()));
+				MF_TRY_HIP(hipMemcpy(p->long_rows[kind], lg.data(), lg.size() * sizeof(int), hipMemcpyHostToDevice));
+				if (!sh.empty())
+					MF_TRY_HIP(hipMemcpy(p->short_rows[kind], sh.data(), sh.size() * sizeof(int), hipMemcpyHostToDevice));
+				p->n_long[kind] = (int) lg.size();
+				p->n_short[kind] = (int) sh.size();
+			}
+			if (p->n_long[0] || p->n_long[1] || p->coop_all[0] || p->coop_all[1]) {
+				p->nch_long = nl;
+				p->lds_bytes_long = head + (size_t) nl * per_entry;
+				MF_TRY_HIP(hipFuncSetAttribute((const void *) p->sweep.coop, hipFuncAttributeMaxDynamicSharedMemorySize,
+				                               (int) std::max(p->lds_bytes_long, p->lds_bytes_coop)));
+			}
+			if (p->n_long[0] || p->n_long[1]) {
+				MF_TRY_HIP(hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking));
+				MF_TRY_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+				MF_TRY_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+			}
+		}
 	}
 
 	const size_t nl = (size_t) p->uc * p->K, nr = (size_t) p->items * p->K;
@@ -638,6 +701,13 @@ void mf_plan_destroy(mf_plan *p)
 		(void) hipFree(p->Rbuf[1]);
 	}
 	(void) hipFree(p->best_dev);
+	for (int k = 0; k < 2; ++k) {
+		(void) hipFree(p->long_rows[k]);
+		(void) hipFree(p->short_rows[k]);
+	}
+	if (p->side_stream) (void) hipStreamDestroy(p->side_stream);
+	if (p->ev_fork) (void) hipEventDestroy(p->ev_fork);
+	if (p->ev_join) (void) hipEventDestroy(p->ev_join);
 	(void) hipFree(p->lnorm);
 	(void) hipFree(p->rmax_bits);
 	(void) hipFree(p->ulist);
@@ -855,9 +925,11 @@ int mf_plan_describe(mf_plan *p, char *buf, int buflen)
 {
 	if (!p || !buf || buflen <= 0) return MF_ERR_ARGUMENT;
 	if (p->sweep.dma)
-		snprintf(buf, (size_t) buflen, "sweep_dma_kernel<KT=%d,NPASS=%d> K=%d nch=%d row_bytes=%d lds=%zu coop_nch=%d",
+		snprintf(buf, (size_t) buflen,
+		         "sweep_dma_kernel<KT=%d,NPASS=%d> K=%d nch=%d row_bytes=%d lds=%zu long_rows=%d/%d coop_nch=%d",
 		         p->sweep.kt, p->sweep.kt ? (p->K / 2 + 63) / 64 : p->sweep.kpmax, p->K, p->nch, p->sweep.row_bytes,
-		         p->lds_bytes, p->nch_coop);
+		         p->lds_bytes, p->n_long[0] + (p->coop_all[0] ? p->items : 0), p->n_long[1] + (p->coop_all[1] ? p->uc : 0),
+		         p->coop_all[0] || p->coop_all[1] ? p->nch_coop : p->nch_long);
 	else
 		snprintf(buf, (size_t) buflen, "sweep_kernel<KT=%d,KPMAX=%d> K=%d nch=%d stride=%d lds=%zu",
 		         p->sweep.kt, p->sweep.kpmax, p->K, p->nch, p->stride, p->lds_bytes);

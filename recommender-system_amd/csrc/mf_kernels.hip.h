@@ -43,6 +43,7 @@ struct SweepArgs {
 	const double *__restrict__ X_old;
 	const double *__restrict__ Y_old;
 	double *__restrict__ X_new;
+	const int *__restrict__ rowlist;   // optional: the launch covers rows rowlist[0..nrows) instead of 0..nrows
 };
 
 __device__ __forceinline__ double readlane_f64(double v, int lane)
@@ -61,7 +62,8 @@ __global__ void __launch_bounds__(kWave) sweep_kernel(SweepArgs a)
 	const int nch = a.nch;
 	const int lane = threadIdx.x;
 
-	for (int r = blockIdx.x; r < a.nrows; r += gridDim.x) {
+	for (int it = blockIdx.x; it < a.nrows; it += gridDim.x) {
+		const int r = a.rowlist ? a.rowlist[it] : it;
 		const int beg = a.ptr[r], end = a.ptr[r + 1];
 		const double *__restrict__ xrow = a.X_old + (size_t) r * K;
 
@@ -174,7 +176,8 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 	const unsigned voff = (unsigned) lane * 16u;
 	const unsigned long long ybase = (unsigned long long) a.Y_old;
 
-	for (int r = blockIdx.x; r < a.nrows; r += gridDim.x) {
+	for (int it = blockIdx.x; it < a.nrows; it += gridDim.x) {
+		const int r = a.rowlist ? a.rowlist[it] : it;
 		const int beg = a.ptr[r], end = a.ptr[r + 1];
 		const double2 *__restrict__ xrow2 = reinterpret_cast<const double2 *>(a.X_old + (size_t) r * K);
 
@@ -494,7 +497,8 @@ __global__ void __launch_bounds__(kCoopWaves *kWave) sweep_coop_kernel(SweepArgs
 	const unsigned long long ybase = (unsigned long long) a.Y_old;
 	const int per_round = kCoopProducers * nch;
 
-	for (int r = blockIdx.x; r < a.nrows; r += gridDim.x) {
+	for (int it = blockIdx.x; it < a.nrows; it += gridDim.x) {
+		const int r = a.rowlist ? a.rowlist[it] : it;
 		const int beg = a.ptr[r], end = a.ptr[r + 1];
 		const double2 *__restrict__ xrow2 = reinterpret_cast<const double2 *>(a.X_old + (size_t) r * K);
 		double2 acc[NP];

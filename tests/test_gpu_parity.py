@@ -388,7 +388,7 @@ def test_row_cooperative_sweep_bit_exact(capi, orc, k, monkeypatch):
         if nch:
             monkeypatch.setenv("MF_SWEEP_NCH", nch)
         plan = capi.Plan(150, 700, k, d["alpha"], d["row"], d["col"], d["val"])
-        assert "coop_nch=" in plan.describe() and not plan.describe().endswith("coop_nch=0")
+        assert "long_rows=" in plan.describe() and "long_rows=0/0" not in plan.describe()
         L, R = capi.init_factors(150, 700, k)
         plan.upload(L, R)
         plan.iterate(3)
@@ -407,3 +407,30 @@ def test_multi_shard_item_heavy_instance_cuts_the_items(capi, orc):
         best = capi.backend_run_multi(_inst(capi, d), L, R, [0] * nd)
         assert np.allclose(L, Lo, rtol=1e-9, atol=1e-13) and np.allclose(R, Ro, rtol=1e-9, atol=1e-13), nd
         assert np.array_equal(best, bo), nd
+
+
+@pytest.mark.parametrize("k", [30, 100, 64])
+def test_skewed_instance_long_rows_on_the_cooperative_kernel(capi, orc, k, monkeypatch):
+    """>= 4096 rows with a few very long ones: the plan sends the long rows (and columns) to the row-cooperative
+    kernel on a side stream and the rest to the single-wave kernel; the union must still be the serial result."""
+    rng = np.random.default_rng(k)
+    U, I = 5000, 4500
+    pairs = set()
+    for u in range(U):
+        for j in rng.choice(I, 6, replace=False):
+            pairs.add((u, int(j)))
+    for u in (7, 2500, 4999):                      # three users with ~1500 ratings
+        for j in rng.choice(I, 1500, replace=False):
+            pairs.add((u, int(j)))
+    for j in (3, 4000):                            # two items rated by ~2000 users
+        for u in rng.choice(U, 2000, replace=False):
+            pairs.add((int(u), j))
+    pr = np.array(sorted(pairs), dtype=np.int32)
+    d = dict(iters=2, alpha=1e-4, feats=k, users=U, items=I, row=np.ascontiguousarray(pr[:, 0]),
+             col=np.ascontiguousarray(pr[:, 1]), val=rng.integers(1, 6, len(pr)).astype(np.float64))
+    Lo, Ro, bo = _oracle_run(orc, d)
+    for skew in ("1", "0"):
+        monkeypatch.setenv("MF_SWEEP_SKEW", skew)
+        L, R = capi.init_factors(U, I, k)
+        best = capi.backend_run(_inst(capi, d), L, R)
+        assert np.array_equal(L, Lo) and np.array_equal(R, Ro) and np.array_equal(best, bo), (k, skew)
