@@ -167,3 +167,31 @@ def test_cli_parse_error(capi, tmp_path):
     p.write_text("10 0.1 2 3 4 2 0 0 1.0")
     r = _run_cli(capi, [str(p)])
     assert r.returncode == 255 and r.stderr == "Error: Error in non-zero entry.\n" and r.stdout == ""
+
+
+def test_headers_are_plain_c(tmp_path):
+    """The drop-in boundary must be consumable by the reference's C compiler (gcc, C99, no C++)."""
+    src = tmp_path / "inc.c"
+    src.write_text('#include "matfact_hip.h"\n#include "matfact_host.h"\n'
+                   'int main(void) { mf_problem p; mf_shard s; (void) p; (void) s; '
+                   'return (int) mf_host_block_low(1, 2, 10) - 5 + (MF_OK != 0); }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        "-fsyntax-only", str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_bench_accounting_and_skewed_generator():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    # SURVEY 8d: A_upd(K) = 16 + 16K per update over two sweeps + 16K per owned row
+    nnz, K, U, I = 1000, 100, 50, 20
+    assert b.algorithmic_bytes(nnz, K, U) + b.algorithmic_bytes(nnz, K, I) == nnz * (16 + 16 * K) + 16 * K * (U + I)
+    row, col, val = b.skewed_instance(7, 300, 200, 6000)
+    key = row.astype(np.int64) * 200 + col
+    assert np.all(np.diff(key) > 0) and col.max() < 200 and row.max() == 299
+    lens = np.bincount(row, minlength=300)
+    assert lens.min() >= 20 and lens.max() > 3 * np.median(lens)          # power-law activity
+    pop = np.bincount(col, minlength=200)
+    assert pop.max() > 4 * np.median(pop)                                 # power-law popularity
