@@ -76,6 +76,20 @@ int mf_host_partition_users(int users, int parts, int by_entries, const int64_t 
 /* one line per user with best >= 0 */
 int mf_host_write_out(FILE *f, const int32_t *best, int users);
 
+/* ---- iteration checkpoint (the reference has none): a binary file holding the header of the
+ * instance it belongs to, the number of iterations already done, and L and R.  Resuming reproduces the
+ * uninterrupted run bit for bit (the iteration is deterministic). */
+typedef struct mf_checkpoint_header {
+	char magic[8];            /* "MFCKPT1\0" */
+	int32_t users, items, features;
+	int32_t iters_done;
+	int64_t nnz;
+	double alpha;
+} mf_checkpoint_header;
+int mf_host_checkpoint_write(const char *path, const mf_problem *p, int iters_done, const double *L, const double *R);
+/* L (users x K) and R (items x K) must be allocated by the caller; fails (-1) if the file does not belong to p */
+int mf_host_checkpoint_read(const char *path, const mf_problem *p, int *iters_done, double *L, double *R);
+
 /* ---- synthetic instances: row u has m(u) in [min_row, max_row] distinct sorted columns, ratings in {1..5};
  * everything is a pure function of (seed, u), so any rank can generate any block of users. */
 typedef struct mf_synth {

@@ -35,7 +35,8 @@ HIP_SYMBOLS = [
 HOST_SYMBOLS = [
     "mf_host_parse_strerror", "mf_host_parse_file", "mf_host_parse_buffer", "mf_host_free_problem",
     "mf_host_srandom", "mf_host_random", "mf_host_init_factors", "mf_host_init_factors_block",
-    "mf_host_split_entries", "mf_host_partition_users", "mf_host_write_out", "mf_host_synth_counts",
+    "mf_host_split_entries", "mf_host_partition_users", "mf_host_write_out", "mf_host_checkpoint_write",
+    "mf_host_checkpoint_read", "mf_host_synth_counts",
     "mf_host_synth_fill",
 ]
 

@@ -86,6 +86,45 @@ static int run_with_mats(const char *path, const mf_problem *p, double *L, doubl
 	return rc;
 }
 
+/*
+ * MATFACT_CHECKPOINT=<path> [MATFACT_CHECKPOINT_EVERY=n, default 1000]: write (L, R, iterations done) every n
+ * iterations; MATFACT_RESUME=<path>: start from such a file instead of the random initial factors.  The final
+ * factors and recommendations are bit-identical to an uninterrupted run.
+ */
+static int run_with_checkpoints(const mf_problem *p, double *L, double *R, int32_t *best, int device, int start_iter)
+{
+	const char *ck = getenv("MATFACT_CHECKPOINT");
+	int every = getenv("MATFACT_CHECKPOINT_EVERY") ? atoi(getenv("MATFACT_CHECKPOINT_EVERY")) : 1000;
+	if (every < 1) every = 1;
+	int32_t *row = malloc(sizeof(int32_t) * (size_t) (p->nnz ? p->nnz : 1));
+	int32_t *col = malloc(sizeof(int32_t) * (size_t) (p->nnz ? p->nnz : 1));
+	double *val = malloc(sizeof(double) * (size_t) (p->nnz ? p->nnz : 1));
+	if (!row || !col || !val) return MF_ERR_NO_MEMORY;
+	mf_host_split_entries(p->entries, p->nnz, row, col, val);
+	mf_shard s = {p->users, p->items, p->features, 0, p->users, p->nnz, row, col, val, p->alpha, device, 0, {0, 0}};
+	mf_plan *plan = NULL;
+	int rc = mf_plan_create(&plan, &s);
+	if (rc == MF_OK) rc = mf_plan_upload_factors(plan, L, R);
+	int done = start_iter;
+	while (rc == MF_OK && done < p->iters) {
+		int step = p->iters - done;
+		if (ck && step > every - done % every) step = every - done % every;
+		rc = mf_plan_iterate(plan, step);
+		done += step;
+		if (rc == MF_OK && ck && done < p->iters) {
+			rc = mf_plan_download_factors(plan, L, R);
+			if (rc == MF_OK && mf_host_checkpoint_write(ck, p, done, L, R) != 0) rc = MF_ERR_ARGUMENT;
+		}
+	}
+	if (rc == MF_OK) rc = mf_plan_recommend(plan, best);
+	if (rc == MF_OK) rc = mf_plan_download_factors(plan, L, R);
+	mf_plan_destroy(plan);
+	free(row);
+	free(col);
+	free(val);
+	return rc;
+}
+
 /* util.c:7-10 */
 static void die(const char *error)
 {
@@ -126,8 +165,14 @@ int main(int argc, char **argv)
 	if (getenv("MATFACT_DEVICE")) device = atoi(getenv("MATFACT_DEVICE"));
 	const char *mats = getenv("MATFACT_MATS");
 	const char *devlist = getenv("MATFACT_DEVICES");   /* e.g. "0,1,2,3,4,5,6,7": row-shard over these GPUs */
-	int rc;
-	if (mats) {
+	int rc, start_iter = 0;
+	if (getenv("MATFACT_RESUME")) {
+		if (mf_host_checkpoint_read(getenv("MATFACT_RESUME"), &prob, &start_iter, L, R) != 0)
+			die("MATFACT_RESUME: cannot read the checkpoint or it belongs to another instance.");
+	}
+	if (getenv("MATFACT_CHECKPOINT") || getenv("MATFACT_RESUME")) {
+		rc = run_with_checkpoints(&prob, L, R, best, device, start_iter);
+	} else if (mats) {
 		rc = run_with_mats(mats, &prob, L, R, best, device);
 	} else if (devlist) {
 		int devs[16], nd = 0;

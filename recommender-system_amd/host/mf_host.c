@@ -236,6 +236,50 @@ int mf_host_write_out(FILE *f, const int32_t *best, int users)
 	return 0;
 }
 
+/* ------------------------------------------------------------------------------------ checkpoint */
+
+int mf_host_checkpoint_write(const char *path, const mf_problem *p, int iters_done, const double *L, const double *R)
+{
+	char tmp[4096];
+	if (snprintf(tmp, sizeof tmp, "%s.tmp", path) >= (int) sizeof tmp) return -1;
+	FILE *f = fopen(tmp, "wb");
+	if (!f) return -1;
+	mf_checkpoint_header h;
+	memset(&h, 0, sizeof h);
+	memcpy(h.magic, "MFCKPT1", 8);
+	h.users = p->users;
+	h.items = p->items;
+	h.features = p->features;
+	h.iters_done = iters_done;
+	h.nnz = p->nnz;
+	h.alpha = p->alpha;
+	const size_t nl = (size_t) p->users * p->features, nr = (size_t) p->items * p->features;
+	int ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(L, sizeof(double), nl, f) == nl &&
+	         fwrite(R, sizeof(double), nr, f) == nr;
+	if (fclose(f) == EOF) ok = 0;
+	if (!ok || rename(tmp, path) != 0) {   /* write-then-rename: a crash never leaves a torn checkpoint */
+		remove(tmp);
+		return -1;
+	}
+	return 0;
+}
+
+int mf_host_checkpoint_read(const char *path, const mf_problem *p, int *iters_done, double *L, double *R)
+{
+	FILE *f = fopen(path, "rb");
+	if (!f) return -1;
+	mf_checkpoint_header h;
+	const size_t nl = (size_t) p->users * p->features, nr = (size_t) p->items * p->features;
+	int ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, "MFCKPT1", 8) == 0 && h.users == p->users &&
+	         h.items == p->items && h.features == p->features && h.nnz == p->nnz && h.alpha == p->alpha &&
+	         h.iters_done >= 0 && h.iters_done <= p->iters;
+	ok = ok && fread(L, sizeof(double), nl, f) == nl && fread(R, sizeof(double), nr, f) == nr;
+	fclose(f);
+	if (!ok) return -1;
+	*iters_done = h.iters_done;
+	return 0;
+}
+
 /* ------------------------------------------------------------------------------------- synthetic */
 
 static inline uint64_t splitmix64(uint64_t *x)

@@ -434,3 +434,35 @@ def test_skewed_instance_long_rows_on_the_cooperative_kernel(capi, orc, k, monke
         L, R = capi.init_factors(U, I, k)
         best = capi.backend_run(_inst(capi, d), L, R)
         assert np.array_equal(L, Lo) and np.array_equal(R, Ro) and np.array_equal(best, bo), (k, skew)
+
+
+def test_cli_checkpoint_and_resume_reproduce_the_uninterrupted_run(capi, tmp_path):
+    """MATFACT_CHECKPOINT / MATFACT_RESUME: stop after a checkpoint, resume, get the same bytes."""
+    src = golden_in("inst30-40-10-2-10")
+    ck = str(tmp_path / "state.ckpt")
+    gold = open(os.path.join(GOLDEN, "inst30-40-10-2-10.out"), "rb").read()
+    # full run with checkpoints every 7000 iterations: last checkpoint on disk is at 14000 of 20000
+    r = subprocess.run([capi.CLI_PATH, src], capture_output=True,
+                       env=dict(os.environ, MATFACT_CHECKPOINT=ck, MATFACT_CHECKPOINT_EVERY="7000"))
+    assert r.returncode == 0 and r.stdout == gold
+    hdr = np.fromfile(ck, dtype=np.int32, count=6)
+    assert bytes(np.fromfile(ck, dtype=np.uint8, count=7)) == b"MFCKPT1" and hdr[5] == 14000
+    # resume from iteration 14000: the remaining 6000 iterations give the same recommendations
+    r = subprocess.run([capi.CLI_PATH, src], capture_output=True, env=dict(os.environ, MATFACT_RESUME=ck))
+    assert r.returncode == 0 and r.stdout == gold
+    # and the resumed factors are bit-identical to the golden final factors (checked through a dump)
+    out = str(tmp_path / "final.ckpt")
+    r = subprocess.run([capi.CLI_PATH, src], capture_output=True,
+                       env=dict(os.environ, MATFACT_RESUME=ck, MATFACT_CHECKPOINT=out, MATFACT_CHECKPOINT_EVERY="19999"))
+    assert r.returncode == 0 and r.stdout == gold
+    snap = np.load(os.path.join(GOLDEN, "inst30-40-10-2-10.factors.npz"))
+    # checkpoint at 19999 then one more iteration: compare the 19999-state + 1 iteration through the library
+    inst = capi.parse_file(src)
+    body = np.fromfile(out, dtype=np.float64, offset=40)
+    L = body[:30 * 10].reshape(30, 10).copy()
+    R = body[30 * 10:30 * 10 + 40 * 10].reshape(40, 10).copy()
+    capi.backend_factorize(inst, L, R, iters=1)
+    assert np.array_equal(L, snap["L_full"]) and np.array_equal(R, snap["R_full"])
+    # a checkpoint of another instance is refused
+    r = subprocess.run([capi.CLI_PATH, golden_in("inst0")], capture_output=True, env=dict(os.environ, MATFACT_RESUME=ck))
+    assert r.returncode == 255 and b"MATFACT_RESUME" in r.stderr
