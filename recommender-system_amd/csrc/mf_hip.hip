@@ -775,11 +775,8 @@ int mf_plan_flip(mf_plan *p)
 	return MF_OK;
 }
 
-int mf_plan_iterate(mf_plan *p, int iters)
+static int iterate_eager(mf_plan *p, int iters)
 {
-	if (!p || iters < 0) return MF_ERR_ARGUMENT;
-	if (!p->have_factors) return MF_ERR_STATE;
-	MF_HIP(hipSetDevice(p->device));
 	for (int it = 0; it < iters; ++it) {
 		int rc = launch_sweep(p, 0, 1);
 		if (rc != MF_OK) return rc;
@@ -788,6 +785,45 @@ int mf_plan_iterate(mf_plan *p, int iters)
 		p->cur ^= 1;
 	}
 	return MF_OK;
+}
+
+int mf_plan_iterate(mf_plan *p, int iters)
+{
+	if (!p || iters < 0) return MF_ERR_ARGUMENT;
+	if (!p->have_factors) return MF_ERR_STATE;
+	MF_HIP(hipSetDevice(p->device));
+	// Launch-bound regime (inst1: 100000 iterations of a 13-entry instance, ~4 us per launch): capture an even
+	// number of iterations -- so the ping-pong parity returns to where it started -- into a HIP graph and replay it.
+	// Only for small sweeps; a large sweep is not launch-bound and a graph would pin its arguments for nothing.
+	const char *genv = getenv("MF_GRAPH");   // "0" disables
+	const bool small = (double) p->nnz * p->K < 2e6 && !p->timing && p->n_long[0] == 0 && p->n_long[1] == 0;
+	constexpr int kGraphIters = 32;
+	if (small && iters >= 4 * kGraphIters && !(genv && genv[0] == '0')) {
+		hipGraph_t graph = nullptr;
+		hipGraphExec_t exec = nullptr;
+		const int cur0 = p->cur;
+		hipError_t e = hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal);
+		int rc = MF_OK;
+		if (e == hipSuccess) {
+			rc = iterate_eager(p, kGraphIters);
+			e = hipStreamEndCapture(p->stream, &graph);
+		}
+		if (e == hipSuccess && rc == MF_OK) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+		if (e == hipSuccess && rc == MF_OK) {
+			p->cur = cur0;   // the capture only recorded; kGraphIters is even, so every replay starts from cur0
+			const int replays = iters / kGraphIters;
+			for (int g = 0; g < replays && e == hipSuccess; ++g) e = hipGraphLaunch(exec, p->stream);
+			iters -= replays * kGraphIters;
+		}
+		if (exec) (void) hipGraphExecDestroy(exec);
+		if (graph) (void) hipGraphDestroy(graph);
+		if (rc != MF_OK) return rc;
+		if (e != hipSuccess) {
+			g_last_hip_error = std::string("hip graph path: ") + hipGetErrorString(e);
+			return MF_ERR_HIP;
+		}
+	}
+	return iterate_eager(p, iters);
 }
 
 int mf_plan_recommend(mf_plan *p, int32_t *best)
