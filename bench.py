@@ -119,6 +119,9 @@ def main():
                          "MovieLens is) instead of the uniform generator; single rank, small configs only")
     ap.add_argument("--recommend", action="store_true",
                     help="also time the fused L*R^T masked top-1 step (reported beside, never inside, `value`)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the collective even with one rank (rehearsal of the "
+                         "RCCL code path on a one-GPU box)")
     ap.add_argument("--check", action="store_true",
                     help="after the timed region compare the factors with a single-shard run on rank 0's GPU")
     args = ap.parse_args()
@@ -147,9 +150,18 @@ def main():
     local_dev = local_rank % ndev
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        if "RANK" not in os.environ:
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            # RCCL's kernels on a high-priority stream: the all-reduce of R runs beside the user sweep, whose
+            # workgroups otherwise hold every CU until they drain
+            try:
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+                dist.init_process_group("nccl", device_id=dev, pg_options=opts)
+            except (AttributeError, TypeError):
+                dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
 
@@ -177,14 +189,15 @@ def main():
     # "plan's own stream" to mf_plan_set_stream, which the collective would not be ordered against)
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
-    run = rs.sharded.ShardedFactorization(plan, r_bufs, rank, world, overlap=not args.no_overlap, stream=stream)
+    run = rs.sharded.ShardedFactorization(plan, r_bufs, rank, world, overlap=not args.no_overlap, stream=stream,
+                                          force_collective=args.force_dist)
     plan.upload(Lb, R0)
     del Lb, R0
     t_setup = time.time() - t_setup
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -201,7 +214,7 @@ def main():
     tm = plan.timing_read()
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
@@ -281,7 +294,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     plan.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

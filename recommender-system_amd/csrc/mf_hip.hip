@@ -624,7 +624,10 @@ int mf_plan_create(mf_plan **out, const mf_shard *s)
 			for (int kind = 0; kind < 2 && nl >= 4; ++kind) {
 				const std::vector<int> &pt = kind == 0 ? cptr : rptr;
 				const int nrows = kind == 0 ? p->items : p->uc;
-				if (p->max_row_len[kind] < t_long) continue;
+				// ... and only rows well above the average count as long: when every row is equally long (the cfg4
+				// twin: 1000 items x 1000 entries) there is no skew to fix and the single-wave kernel is the faster one
+				const int t_kind = getenv("MF_SWEEP_LONG") ? t_long : std::max(t_long, (int) std::min<long long>(4 * (long long) (p->nnz / std::max(nrows, 1)), 2000000000ll));
+				if (p->max_row_len[kind] < t_kind) continue;
 				if (est_us < 50.0 && nrows < 4096 && !getenv("MF_SWEEP_LONG")) {
 					if (nc >= 8 || getenv("MF_SWEEP_NCH")) {
 						p->coop_all[kind] = true;
@@ -634,7 +637,7 @@ int mf_plan_create(mf_plan **out, const mf_shard *s)
 					continue;
 				}
 				std::vector<int> lg, sh;
-				for (int r = 0; r < nrows; ++r) (pt[(size_t) r + 1] - pt[r] >= t_long ? lg : sh).push_back(r);
+				for (int r = 0; r < nrows; ++r) (pt[(size_t) r + 1] - pt[r] >= t_kind ? lg : sh).push_back(r);
 				MF_TRY(dev_alloc(&p->long_rows[kind], lg.size()));
 				MF_TRY(dev_alloc(&p->short_rows[kind], sh.size()));
 				MF_TRY_HIP(hipMemcpy(p->long_rows[kind], lg.data(), lg.size() * sizeof(int), hipMemcpyHostToDevice));

@@ -27,13 +27,14 @@ def shard_bounds(users, world, row_ptr=None, by_entries=True):
 class ShardedFactorization:
     """Runs iterations of one shard and keeps the two R generations in torch tensors for the collective."""
 
-    def __init__(self, plan, r_buffers, rank, world, group=None, overlap=True, stream=None):
+    def __init__(self, plan, r_buffers, rank, world, group=None, overlap=True, stream=None, force_collective=False):
         """`stream`: a NON-default torch.cuda.Stream for GPU runs.  The plan's kernels and the collective must be
         ordered on the same stream; the default stream's handle is 0, which mf_plan_set_stream reads as "use the
         plan's own stream", so it cannot be used here.  None only for CPU stand-in plans (tests)."""
         self.plan, self.rank, self.world, self.group, self.overlap = plan, rank, world, group, overlap
         self.r = list(r_buffers)          # two tensors, items x K, same device as the plan
         self._ptr = {int(t.data_ptr()): t for t in self.r}
+        self.force_collective = force_collective
         self.stream = stream
         if stream is not None:
             if int(stream.cuda_stream) == 0:
@@ -57,7 +58,7 @@ class ShardedFactorization:
 
     def _step(self):
         p = self.plan
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             p.sweep_items(True)
             p.sweep_users()
             p.flip()

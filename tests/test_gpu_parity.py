@@ -382,7 +382,14 @@ def test_single_process_multi_shard_run(capi, orc, tmp_path):
 def test_row_cooperative_sweep_bit_exact(capi, orc, k, monkeypatch):
     """Few rows, some of them long (>= 128 entries): the 8-wave row-cooperative kernel (producers gather and
     scale, one accumulator wave adds in order) must reproduce the serial sums bit for bit, for every tile size."""
-    d = random_instance(500 + k, 150, 700, k, density=0.45, iters=3, alpha=2e-4, empty_rows=(5,), float_ratings=True)
+    rng = np.random.default_rng(500 + k)
+    mask = rng.random((150, 700)) < 0.08
+    mask[:10, :] = rng.random((10, 700)) < 0.9      # ten users with ~630 ratings (mean ~95)
+    mask[:, :5] = True                               # five items rated by everybody (mean ~20)
+    mask[5, :] = False
+    row, col = np.nonzero(mask)
+    d = dict(iters=3, alpha=2e-4, feats=k, users=150, items=700, row=row.astype(np.int32), col=col.astype(np.int32),
+             val=(rng.random(len(row)) * 4 + 1))
     Lo, Ro, bo = _oracle_run(orc, d)
     for nch in (None, "5", "32"):
         if nch:
