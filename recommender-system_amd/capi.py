@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libmatfact_hip.so")
+# MF_HIP_LIB: alternative build of the same library (A/B timing of kernel variants); never a different backend
+HIP_LIB_PATH = os.environ.get("MF_HIP_LIB") or os.path.join(_HERE, "csrc", "libmatfact_hip.so")
 HOST_LIB_PATH = os.path.join(_HERE, "host", "libmatfact_host.so")
 CLI_PATH = os.path.join(_HERE, "host", "matFact")
 
