@@ -37,27 +37,29 @@ struct SweepVariant {
 	int dma;        // 1: LDS-DMA form
 	int row_bytes;  // LDS tile row stride in bytes (DMA form)
 	int xs_bytes;   // LDS bytes in front of the tile (DMA form)
-	SweepFn coop;   // row-cooperative form for launches with few rows (DMA variants only)
+	SweepFn coop;   // row-cooperative form for tiny sweeps (compile-time-K DMA variants only)
+	SweepFn prod;   // products form for segments of extreme rows (all DMA variants)
 };
 
 template <int KT, int KP>
 constexpr SweepVariant variant()
 {
-	return SweepVariant{mf::sweep_kernel<KT, KP>, KT, KP, 0, 0, 0, nullptr};
+	return SweepVariant{mf::sweep_kernel<KT, KP>, KT, KP, 0, 0, 0, nullptr, nullptr};
 }
 
 template <int KT>
 constexpr SweepVariant dma_variant()
 {
 	return SweepVariant{mf::sweep_dma_kernel<KT, mf::DmaGeom<KT>::kPasses>, KT, 0, 1, mf::DmaGeom<KT>::kStride,
-	                    mf::DmaGeom<KT>::kXsBytes, mf::sweep_coop_kernel<KT>};
+	                    mf::DmaGeom<KT>::kXsBytes, mf::sweep_coop_kernel<KT>,
+	                    mf::sweep_dma_kernel<KT, mf::DmaGeom<KT>::kPasses, true>};
 }
 
 // run-time even K <= 128 * NPASS through the LDS-DMA kernel (row_bytes / xs_bytes filled in per plan)
 template <int NPASS>
 constexpr SweepVariant dma_generic_variant()
 {
-	return SweepVariant{mf::sweep_dma_kernel<0, NPASS>, 0, NPASS, 1, 0, 0, nullptr};
+	return SweepVariant{mf::sweep_dma_kernel<0, NPASS>, 0, NPASS, 1, 0, 0, nullptr, mf::sweep_dma_kernel<0, NPASS, true>};
 }
 
 // K-specialised instances for the K of the bundled samples and of the BASELINE configs, then generic ones.
@@ -126,8 +128,13 @@ struct mf_plan {
 	// row-cooperative kernel on a side stream, the others stay on the single-wave kernel
 	int *long_rows[2] = {nullptr, nullptr}, *short_rows[2] = {nullptr, nullptr};
 	int n_long[2] = {0, 0}, n_short[2] = {0, 0};
-	int nch_long = 0;
-	size_t lds_bytes_long = 0;
+	// extreme rows of LARGE sweeps: 256-entry segments -> scaled rows in `scratch` -> ordered sum
+	int n_seg[2] = {0, 0};
+	int *seg_row[2] = {nullptr, nullptr}, *seg_beg[2] = {nullptr, nullptr}, *seg_end[2] = {nullptr, nullptr};
+	long long *seg_out[2] = {nullptr, nullptr}, *lr_sbeg[2] = {nullptr, nullptr};
+	int *lr_cnt[2] = {nullptr, nullptr};
+	double *scratch = nullptr;
+	size_t scratch_entries = 0;
 	// tiny sweeps (a few us of data): ONE cooperative launch over all rows; a fork/join costs more than it saves
 	int nch_coop = 0;
 	size_t lds_bytes_coop = 0;
@@ -146,7 +153,7 @@ namespace {
 int choose_sweep(mf_plan *p)
 {
 	const int K = p->K;
-	p->sweep = SweepVariant{nullptr, 0, 0, 0, 0, 0, nullptr};
+	p->sweep = SweepVariant{nullptr, 0, 0, 0, 0, 0, nullptr, nullptr};
 	const char *impl = getenv("MF_SWEEP_IMPL");   // "dma" (default) | "reg": register-staged form only
 	const bool allow_dma = !(impl && strcmp(impl, "reg") == 0);
 	if (allow_dma)
@@ -421,6 +428,10 @@ int launch_sweep(mf_plan *p, int kind, int seed)
 		a.X_new = p->Lbuf[nxt];
 	}
 	a.rowlist = nullptr;
+	a.seg_row = a.seg_beg = a.seg_end = nullptr;
+	a.seg_out = nullptr;
+	a.scratch = nullptr;
+	a.scratch_entries = 0;
 	if (a.nrows <= 0) return MF_OK;
 	const bool few_rows = a.nrows < 4096;
 	const bool coop = p->coop_all[kind];
@@ -438,22 +449,45 @@ int launch_sweep(mf_plan *p, int kind, int seed)
 	}
 	void *args[] = {&a};
 	if (p->n_long[kind] > 0) {
-		// long rows: cooperative kernel on the side stream, concurrently with the short rows on the main stream
+		// extreme rows on the side stream, concurrently with the other rows on the main stream:
+		//   products kernel over their 256-entry segments -> ordered sum per (row, 16-column slice)
 		mf::SweepArgs b = a;
-		b.nrows = p->n_long[kind];
-		b.rowlist = p->long_rows[kind];
-		b.nch = p->nch_long;
+		b.nrows = p->n_seg[kind];
+		b.rowlist = nullptr;
+		b.nch = p->nch;
+		b.seg_row = p->seg_row[kind];
+		b.seg_beg = p->seg_beg[kind];
+		b.seg_end = p->seg_end[kind];
+		b.seg_out = p->seg_out[kind];
+		b.scratch = p->scratch;
+		b.scratch_entries = p->scratch_entries;
 		void *bargs[] = {&b};
+		mf::OrderedSumArgs o;
+		o.nrows = p->n_long[kind];
+		o.K = p->K;
+		o.seed = seed;
+		o.nslices = (p->K + 15) / 16;
+		o.row = p->long_rows[kind];
+		o.sbeg = p->lr_sbeg[kind];
+		o.cnt = p->lr_cnt[kind];
+		o.scratch = p->scratch;
+		o.scratch_entries = p->scratch_entries;
+		o.X_old = a.X_old;
+		o.X_new = a.X_new;
+		void *oargs[] = {&o};
 		MF_HIP(hipEventRecord(p->ev_fork, p->stream));
 		MF_HIP(hipStreamWaitEvent(p->side_stream, p->ev_fork, 0));
-		MF_HIP(hipLaunchKernel((const void *) p->sweep.coop, dim3(b.nrows), dim3(mf::kCoopWaves * mf::kWave), bargs,
-		                       p->lds_bytes_long, p->side_stream));
+		MF_HIP(hipLaunchKernel((const void *) p->sweep.prod, dim3(b.nrows), dim3(mf::kWave), bargs, p->lds_bytes,
+		                       p->side_stream));
+		MF_HIP(hipLaunchKernel((const void *) mf::ordered_sum_kernel, dim3(o.nrows * o.nslices), dim3(mf::kWave), oargs,
+		                       0, p->side_stream));
 		MF_HIP(hipEventRecord(p->ev_join, p->side_stream));
 		a.nrows = p->n_short[kind];
 		a.rowlist = p->short_rows[kind];
+		a.nch = p->nch;   // the extreme rows are gone: the occupancy-friendly chunk size is right again
 		if (a.nrows > 0)
-			MF_HIP(hipLaunchKernel((const void *) fn, dim3(std::min(a.nrows, 1 << 20)), dim3(block), args, lds,
-			                       p->stream));
+			MF_HIP(hipLaunchKernel((const void *) p->sweep.fn, dim3(std::min(a.nrows, 1 << 20)), dim3(mf::kWave), args,
+			                       p->lds_bytes, p->stream));
 		MF_HIP(hipStreamWaitEvent(p->stream, p->ev_join, 0));
 	} else {
 		MF_HIP(hipLaunchKernel((const void *) fn, dim3(grid), dim3(block), args, lds, p->stream));
@@ -606,7 +640,7 @@ int mf_plan_create(mf_plan **out, const mf_shard *s)
 		// chunks) would exceed roughly a quarter of the bandwidth time of the whole sweep (nnz * 8K bytes at
 		// ~7 TB/s): len > 4e-6 * nnz * K, and never below 128 entries.  cfg4 has none; a power-law instance a few.
 		const char *skew_env = getenv("MF_SWEEP_SKEW");   // "0" disables the split
-		if (p->sweep.coop && !(skew_env && skew_env[0] == '0')) {
+		if (p->sweep.prod && !(skew_env && skew_env[0] == '0')) {
 			const size_t per_entry = 2 * (size_t) mf::kCoopProducers * (size_t) p->sweep.row_bytes;
 			const size_t head = (size_t) p->sweep.xs_bytes;
 			int nl = (int) std::min<size_t>(32, (kLdsPerCu - 4096 - head) / per_entry);
@@ -621,7 +655,9 @@ int mf_plan_create(mf_plan **out, const mf_shard *s)
 			// launches of ML100k) costs more than the split saves: use one cooperative launch for all rows there
 			const double est_us = (double) p->nnz * 8.0 * p->K / 6e12 * 1e6;
 			const int nc = (int) std::min<size_t>(32, (48 * 1024) / per_entry);
-			for (int kind = 0; kind < 2 && nl >= 4; ++kind) {
+			long long scratch_entries = 0;
+			(void) nl;
+			for (int kind = 0; kind < 2; ++kind) {
 				const std::vector<int> &pt = kind == 0 ? cptr : rptr;
 				const int nrows = kind == 0 ? p->items : p->uc;
 				// ... and only rows well above the average count as long: when every row is equally long (the cfg4
@@ -629,7 +665,7 @@ int mf_plan_create(mf_plan **out, const mf_shard *s)
 				const int t_kind = getenv("MF_SWEEP_LONG") ? t_long : std::max(t_long, (int) std::min<long long>(4 * (long long) (p->nnz / std::max(nrows, 1)), 2000000000ll));
 				if (p->max_row_len[kind] < t_kind) continue;
 				if (est_us < 50.0 && nrows < 4096 && !getenv("MF_SWEEP_LONG")) {
-					if (nc >= 8 || getenv("MF_SWEEP_NCH")) {
+					if (p->sweep.coop && (nc >= 8 || getenv("MF_SWEEP_NCH"))) {
 						p->coop_all[kind] = true;
 						p->nch_coop = getenv("MF_SWEEP_NCH") ? nl : nc;
 						p->lds_bytes_coop = head + (size_t) p->nch_coop * per_entry;
@@ -645,14 +681,47 @@ int mf_plan_create(mf_plan **out, const mf_shard *s)
 					MF_TRY_HIP(hipMemcpy(p->short_rows[kind], sh.data(), sh.size() * sizeof(int), hipMemcpyHostToDevice));
 				p->n_long[kind] = (int) lg.size();
 				p->n_short[kind] = (int) sh.size();
+				// segments of 256 entries; scratch offsets in entry units, rows back to back
+				constexpr int kSeg = 256;
+				std::vector<int> srow, sbeg, send, lcnt;
+				std::vector<long long> sout, lbeg;
+				long long off = 0;
+				for (int r : lg) {
+					const int b = pt[r], e = pt[(size_t) r + 1];
+					lbeg.push_back(off);
+					lcnt.push_back(e - b);
+					for (int c = b; c < e; c += kSeg) {
+						srow.push_back(r);
+						sbeg.push_back(c);
+						send.push_back(std::min(e, c + kSeg));
+						sout.push_back(off + (c - b));
+					}
+					off += e - b;
+				}
+				scratch_entries = std::max(scratch_entries, off);
+				p->n_seg[kind] = (int) srow.size();
+				MF_TRY(dev_alloc(&p->seg_row[kind], srow.size()));
+				MF_TRY(dev_alloc(&p->seg_beg[kind], srow.size()));
+				MF_TRY(dev_alloc(&p->seg_end[kind], srow.size()));
+				MF_TRY(dev_alloc(&p->seg_out[kind], srow.size()));
+				MF_TRY(dev_alloc(&p->lr_sbeg[kind], lg.size()));
+				MF_TRY(dev_alloc(&p->lr_cnt[kind], lg.size()));
+				MF_TRY_HIP(hipMemcpy(p->seg_row[kind], srow.data(), srow.size() * sizeof(int), hipMemcpyHostToDevice));
+				MF_TRY_HIP(hipMemcpy(p->seg_beg[kind], sbeg.data(), srow.size() * sizeof(int), hipMemcpyHostToDevice));
+				MF_TRY_HIP(hipMemcpy(p->seg_end[kind], send.data(), srow.size() * sizeof(int), hipMemcpyHostToDevice));
+				MF_TRY_HIP(hipMemcpy(p->seg_out[kind], sout.data(), srow.size() * sizeof(long long), hipMemcpyHostToDevice));
+				MF_TRY_HIP(hipMemcpy(p->lr_sbeg[kind], lbeg.data(), lg.size() * sizeof(long long), hipMemcpyHostToDevice));
+				MF_TRY_HIP(hipMemcpy(p->lr_cnt[kind], lcnt.data(), lg.size() * sizeof(int), hipMemcpyHostToDevice));
 			}
-			if (p->n_long[0] || p->n_long[1] || p->coop_all[0] || p->coop_all[1]) {
-				p->nch_long = nl;
-				p->lds_bytes_long = head + (size_t) nl * per_entry;
+			if (p->coop_all[0] || p->coop_all[1])
 				MF_TRY_HIP(hipFuncSetAttribute((const void *) p->sweep.coop, hipFuncAttributeMaxDynamicSharedMemorySize,
-				                               (int) std::max(p->lds_bytes_long, p->lds_bytes_coop)));
-			}
+				                               (int) p->lds_bytes_coop));
 			if (p->n_long[0] || p->n_long[1]) {
+				MF_TRY_HIP(hipFuncSetAttribute((const void *) p->sweep.prod, hipFuncAttributeMaxDynamicSharedMemorySize,
+				                               (int) p->lds_bytes));
+				// [16-column slice][entry][16 doubles]; 8 entries of padding per slice: the last block of a row is read whole
+				p->scratch_entries = (size_t) scratch_entries + 8;
+				MF_TRY(dev_alloc(&p->scratch, p->scratch_entries * 16 * (size_t) ((p->K + 15) / 16)));
 				MF_TRY_HIP(hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking));
 				MF_TRY_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
 				MF_TRY_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
@@ -707,7 +776,14 @@ void mf_plan_destroy(mf_plan *p)
 	for (int k = 0; k < 2; ++k) {
 		(void) hipFree(p->long_rows[k]);
 		(void) hipFree(p->short_rows[k]);
+		(void) hipFree(p->seg_row[k]);
+		(void) hipFree(p->seg_beg[k]);
+		(void) hipFree(p->seg_end[k]);
+		(void) hipFree(p->seg_out[k]);
+		(void) hipFree(p->lr_sbeg[k]);
+		(void) hipFree(p->lr_cnt[k]);
 	}
+	(void) hipFree(p->scratch);
 	if (p->side_stream) (void) hipStreamDestroy(p->side_stream);
 	if (p->ev_fork) (void) hipEventDestroy(p->ev_fork);
 	if (p->ev_join) (void) hipEventDestroy(p->ev_join);
@@ -968,7 +1044,7 @@ int mf_plan_describe(mf_plan *p, char *buf, int buflen)
 		         "sweep_dma_kernel<KT=%d,NPASS=%d> K=%d nch=%d row_bytes=%d lds=%zu long_rows=%d/%d coop_nch=%d",
 		         p->sweep.kt, p->sweep.kt ? (p->K / 2 + 63) / 64 : p->sweep.kpmax, p->K, p->nch, p->sweep.row_bytes,
 		         p->lds_bytes, p->n_long[0] + (p->coop_all[0] ? p->items : 0), p->n_long[1] + (p->coop_all[1] ? p->uc : 0),
-		         p->coop_all[0] || p->coop_all[1] ? p->nch_coop : p->nch_long);
+		         p->coop_all[0] || p->coop_all[1] ? p->nch_coop : 0);
 	else
 		snprintf(buf, (size_t) buflen, "sweep_kernel<KT=%d,KPMAX=%d> K=%d nch=%d stride=%d lds=%zu",
 		         p->sweep.kt, p->sweep.kpmax, p->K, p->nch, p->stride, p->lds_bytes);

@@ -44,6 +44,14 @@ struct SweepArgs {
 	const double *__restrict__ Y_old;
 	double *__restrict__ X_new;
 	const int *__restrict__ rowlist;   // optional: the launch covers rows rowlist[0..nrows) instead of 0..nrows
+	// products mode (extreme rows): the launch covers SEGMENTS of rows; segment s = entries [seg_beg, seg_end) of row
+	// seg_row, whose scaled rows e_n * Y[idx_n][:] go to the scratch buffer at entry offset seg_out + (n - seg_beg)
+	const int *__restrict__ seg_row;
+	const int *__restrict__ seg_beg;
+	const int *__restrict__ seg_end;
+	const long long *__restrict__ seg_out;
+	double *__restrict__ scratch;
+	size_t scratch_entries;            // entries per 16-column slice of the scratch buffer
 };
 
 __device__ __forceinline__ double readlane_f64(double v, int lane)
@@ -160,7 +168,11 @@ struct DmaGeom {
 // KT > 0: K is a compile-time constant (phase A fully unrolled).  KT == 0: any even K up to 128*NPASS at run
 // time (phase A unrolled by four) -- same data movement, so an unusual K does not fall back to the
 // register-staged kernel.
-template <int KT, int NPASS>
+// PRODUCTS = true: the "extreme row" form -- one wave per SEGMENT of a very long row; instead of accumulating, the
+// scaled rows p_n[k] = e_n * y_n[k] (the rounded product the serial loop adds) are stored to a scratch buffer in
+// entry order, and ordered_sum_kernel adds them up in that order afterwards.  Thousands of segments run in
+// parallel, so a row rated by every user costs a chip-wide pass plus one serial chain of adds.
+template <int KT, int NPASS, bool PRODUCTS = false>
 __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 {
 	const int K = KT > 0 ? KT : a.K;
@@ -177,8 +189,9 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 	const unsigned long long ybase = (unsigned long long) a.Y_old;
 
 	for (int it = blockIdx.x; it < a.nrows; it += gridDim.x) {
-		const int r = a.rowlist ? a.rowlist[it] : it;
-		const int beg = a.ptr[r], end = a.ptr[r + 1];
+		const int r = PRODUCTS ? a.seg_row[it] : (a.rowlist ? a.rowlist[it] : it);
+		const int beg = PRODUCTS ? a.seg_beg[it] : a.ptr[r];
+		const int end = PRODUCTS ? a.seg_end[it] : a.ptr[r + 1];
 		const double2 *__restrict__ xrow2 = reinterpret_cast<const double2 *>(a.X_old + (size_t) r * K);
 
 		double2 acc[NP];
@@ -259,6 +272,28 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 				}
 				e = a.c2 * (my_val - dot);
 			}
+			if (PRODUCTS) {
+				// scratch layout: [k-slice of 16 columns][entry][16 doubles] -- every (slice, entry) is one aligned
+				// 128-B line and a slice is contiguous over the entries, so ordered_sum_kernel streams it linearly
+				const char *tb = tile + voff;
+				const size_t pos = (size_t) (a.seg_out[it] + (c - beg));
+				for (int n = 0; n < cnt; ++n) {
+					const double en = readlane_f64(e, n);
+#pragma unroll
+					for (int p = 0; p < NP; ++p) {
+						const int q = lane + kWave * p;   // 16-B piece: slice q / 8, position q % 8 in its line
+						if (q < P) {
+							double2 t = *reinterpret_cast<const double2 *>(tb + n * S + 1024 * p);
+							t.x = en * t.x;
+							t.y = en * t.y;
+							*reinterpret_cast<double2 *>(a.scratch + (((size_t) (q >> 3) * a.scratch_entries + pos + n) << 4) +
+							                             2 * (q & 7)) = t;
+						}
+					}
+				}
+				__syncthreads();
+				continue;
+			}
 			// ---- phase B
 			const char *tb = tile + voff;
 			int n = 0;
@@ -294,12 +329,100 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 			}
 			__syncthreads();   // tile is overwritten by the next chunk's DMA
 		}
-		double2 *__restrict__ out2 = reinterpret_cast<double2 *>(a.X_new + (size_t) r * K);
+		if (!PRODUCTS) {
+			double2 *__restrict__ out2 = reinterpret_cast<double2 *>(a.X_new + (size_t) r * K);
 #pragma unroll
-		for (int p = 0; p < NP; ++p) {
-			const int q = lane + kWave * p;
-			if (q < P) out2[q] = acc[p];
+			for (int p = 0; p < NP; ++p) {
+				const int q = lane + kWave * p;
+				if (q < P) out2[q] = acc[p];
+			}
 		}
+	}
+}
+
+// Ordered sum of the scaled rows of one extreme row: X_new[r][k] = (...((seed + p_0[k]) + p_1[k]) + ...), the
+// serial accumulation order.  One wave per (row, 16-column slice).  The slice is contiguous over the entries
+// (128 B each), so ONE LDS-DMA instruction brings a block of 8 consecutive entries (1 KiB, lane-linear) into a
+// slot of a 32-slot LDS ring, and the wave keeps 31 blocks -- 248 entries -- in flight ahead of the block it is
+// adding: that hides the ~2 us read latency behind the only true critical path, the chain of dependent adds.
+// The DMA and its s_waitcnt are inline asm with hand-counted vmcnt (hipcc would otherwise wait vmcnt(0) before
+// every LDS read that may alias a pending LDS-DMA); no prefetch registers exist, so nothing can be sunk or
+// spilled.  Every lane (piece = lane & 7) walks the 8 entries of a block in order; the eight lane groups hold
+// identical sums.
+struct OrderedSumArgs {
+	int nrows, K, seed, nslices;
+	const int *__restrict__ row;          // extreme row ids
+	const long long *__restrict__ sbeg;   // first scratch entry of the row
+	const int *__restrict__ cnt;          // entries of the row
+	const double *__restrict__ scratch;   // [slice][entry][16], each slice padded by 8 entries
+	size_t scratch_entries;
+	const double *__restrict__ X_old;
+	double *__restrict__ X_new;
+};
+
+constexpr int kRing = 32;   // LDS ring slots of 1 KiB
+
+__global__ void __launch_bounds__(kWave) ordered_sum_kernel(OrderedSumArgs a)
+{
+	__shared__ __attribute__((aligned(1024))) char ring[kRing * 1024];
+	const int lane = threadIdx.x, K = a.K;
+	const unsigned ring_base = (unsigned) (unsigned long long) (__attribute__((address_space(3))) char *) ring;
+	const char *my = ring + 16 * (lane & 7);          // this lane's piece inside an entry
+	const int total = a.nrows * a.nslices;
+	for (int it = blockIdx.x; it < total; it += gridDim.x) {
+		const int li = it / a.nslices, slice = it % a.nslices;
+		const int r = a.row[li], cnt = a.cnt[li];
+		const int k0 = slice * 16 + 2 * (lane & 7);       // this lane's two columns (all 8 lane groups agree)
+		const bool live = k0 < K;                         // K is even: k0 + 1 < K too
+		double2 acc = (a.seed && live) ? *reinterpret_cast<const double2 *>(a.X_old + (size_t) r * K + k0)
+		                               : make_double2(0.0, 0.0);
+		// block b of the row in this slice: 8 entries = 1 KiB at ((slice * entries + sbeg + 8b) * 128) bytes
+		const char *src = reinterpret_cast<const char *>(
+		                      a.scratch + (((size_t) slice * a.scratch_entries + (size_t) a.sbeg[li]) << 4)) +
+		                  16 * lane;
+		const int nblk = (cnt + 7) >> 3;
+
+		// every ordinary load above must have landed before the hand-counted region starts
+		asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+		auto issue = [&](int b) {
+			const char *g = src + (size_t) b * 1024;
+			const unsigned m0 = ring_base + (unsigned) (b & (kRing - 1)) * 1024u;
+			asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0) : "memory");
+		};
+		auto add_block = [&](int b, int entries) {
+			const char *slot = my + (b & (kRing - 1)) * 1024;
+			if (entries == 8) {
+				double2 v[8];
+#pragma unroll
+				for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const double2 *>(slot + 128 * e);
+#pragma unroll
+				for (int e = 0; e < 8; ++e) {
+					acc.x = acc.x + v[e].x;
+					acc.y = acc.y + v[e].y;
+				}
+			} else {
+				for (int e = 0; e < entries; ++e) {
+					const double2 v = *reinterpret_cast<const double2 *>(slot + 128 * e);
+					acc.x = acc.x + v.x;
+					acc.y = acc.y + v.y;
+				}
+			}
+		};
+		const int ahead = min(nblk, kRing - 1);
+		for (int b = 0; b < ahead; ++b) issue(b);
+		int b = 0;
+		// steady state: kRing-1 blocks are issued beyond b-1, so block b has landed once at most kRing-2 newer DMAs
+		// are outstanding; after adding it, its predecessor's slot is refilled (its LDS reads were consumed by the adds)
+		for (; b + (kRing - 1) < nblk; ++b) {
+			asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+			add_block(b, 8);
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			issue(b + kRing - 1);
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		for (; b < nblk; ++b) add_block(b, min(8, cnt - 8 * b));
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the ring is reused by the next (row, slice)
+		if (live && lane < 8) *reinterpret_cast<double2 *>(a.X_new + (size_t) r * K + k0) = acc;
 	}
 }
 
