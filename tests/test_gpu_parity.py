@@ -473,3 +473,34 @@ def test_cli_checkpoint_and_resume_reproduce_the_uninterrupted_run(capi, tmp_pat
     # a checkpoint of another instance is refused
     r = subprocess.run([capi.CLI_PATH, golden_in("inst0")], capture_output=True, env=dict(os.environ, MATFACT_RESUME=ck))
     assert r.returncode == 255 and b"MATFACT_RESUME" in r.stderr
+
+
+def test_randomised_shapes_all_paths_bit_exact(capi, orc, monkeypatch):
+    """A seeded campaign over shapes, K (odd, even, specialised, generic), densities, skew and path overrides:
+    single-wave DMA (compile-time and run-time K), register-staged (odd K), cooperative-all (tiny skewed),
+    extreme-row products + ordered sum (forced by MF_SWEEP_LONG), HIP-graph replay (many iterations).
+    Everything must equal the oracle bit for bit."""
+    rng = np.random.default_rng(20261004)
+    ks = [1, 2, 3, 6, 10, 14, 20, 30, 31, 50, 64, 66, 100, 128, 130, 200, 256]
+    for case in range(48):
+        k = int(ks[case % len(ks)])
+        u = int(rng.integers(1, 400))
+        i = int(rng.integers(1, 400))
+        dens = float(rng.choice([0.02, 0.1, 0.4]))
+        mask = rng.random((u, i)) < dens
+        if case % 3 == 0 and u > 4 and i > 4:          # plant skew: a few dense rows and columns
+            mask[rng.integers(0, u, 2), :] = rng.random((2, i)) < 0.95
+            mask[:, rng.integers(0, i, 2)] = rng.random((u, 2)) < 0.95
+        row, col = np.nonzero(mask)
+        iters = 130 if case % 8 == 5 else int(rng.integers(1, 4))     # >= 128 iterations: the graph path
+        d = dict(iters=iters, alpha=1e-3 / max(k, 1), feats=k, users=u, items=i, row=row.astype(np.int32),
+                 col=col.astype(np.int32), val=rng.integers(1, 6, len(row)).astype(np.float64))
+        if case % 4 == 1:
+            monkeypatch.setenv("MF_SWEEP_LONG", "40")   # force the extreme-row path on small instances
+        else:
+            monkeypatch.delenv("MF_SWEEP_LONG", raising=False)
+        L, R = capi.init_factors(u, i, k)
+        best = capi.backend_run(_inst(capi, d), L, R)
+        Lo, Ro, bo = _oracle_run(orc, d)
+        assert np.array_equal(L, Lo) and np.array_equal(R, Ro), (case, u, i, k, dens, iters)
+        assert np.array_equal(best, bo), (case, u, i, k)
