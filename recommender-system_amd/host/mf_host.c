@@ -8,6 +8,9 @@
 #include <errno.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 /* ------------------------------------------------------------------------------------------ parsing */
 
@@ -58,7 +61,7 @@ static int take_double(const char **cur, const char *end, double *out)
 	return 1;
 }
 
-int mf_host_parse_buffer(const char *text, size_t len, mf_problem *p)
+static int parse_buffer_sequential(const char *text, size_t len, mf_problem *p)
 {
 	memset(p, 0, sizeof *p);
 	const char *cur = text, *end = text + len;
@@ -89,6 +92,146 @@ int mf_host_parse_buffer(const char *text, size_t len, mf_problem *p)
 	p->items = items;
 	p->nnz = nnz > 0 ? nnz : 0;
 	p->entries = e;
+	return MF_PARSE_OK;
+}
+
+/* ---- parallel body parse.  The entries are 3*nnz white-space separated tokens; threads count the
+ * tokens of their slice of the buffer, a prefix sum tells every slice which token it starts with, and the slices
+ * parse in parallel.  A token must be consumed WHOLE by its field (fscanf would split "3.5" read with %d into "3"
+ * and ".5"): anything else -- and any failure -- abandons the fast path, and the sequential parser above decides,
+ * so results and error strings are always those of the sequential (== fscanf) semantics. */
+static inline int is_space(char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
+
+/* whole-token int: optional sign, digits only */
+static int token_int(const char *b, const char *e, int *out)
+{
+	int neg = 0;
+	if (b < e && (*b == '+' || *b == '-')) neg = (*b++ == '-');
+	if (b >= e || e - b > 10) return 0;
+	long long v = 0;
+	for (; b < e; ++b) {
+		if (*b < '0' || *b > '9') return 0;
+		v = v * 10 + (*b - '0');
+	}
+	if (v > 0x7fffffffLL) return 0;
+	*out = (int) (neg ? -v : v);
+	return 1;
+}
+
+/* whole-token decimal "ddd[.ddd]" with <= 15 significant digits: mantissa and 10^k are exact doubles, so the one
+ * IEEE division is the correctly rounded value (Clinger's fast path) == strtod's result; anything else -> strtod */
+static int token_double(const char *b, const char *e, double *out)
+{
+	static const double p10[] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15};
+	const char *s = b;
+	int neg = 0, digits = 0, frac = 0, seen_dot = 0;
+	if (s < e && (*s == '+' || *s == '-')) neg = (*s++ == '-');
+	long long m = 0;
+	for (; s < e; ++s) {
+		if (*s == '.' && !seen_dot) {
+			seen_dot = 1;
+		} else if (*s >= '0' && *s <= '9') {
+			if (++digits > 15) break;
+			m = m * 10 + (*s - '0');
+			frac += seen_dot;
+		} else {
+			break;
+		}
+	}
+	if (s == e && digits > 0 && digits <= 15) {
+		const double v = (double) m / p10[frac];
+		*out = neg ? -v : v;
+		return 1;
+	}
+	char tmp[64];
+	const size_t n = (size_t) (e - b);
+	if (n == 0 || n >= sizeof tmp) return 0;
+	memcpy(tmp, b, n);
+	tmp[n] = '\0';
+	char *stop = NULL;
+	const double v = strtod(tmp, &stop);
+	if (stop != tmp + n) return 0;
+	*out = v;
+	return 1;
+}
+
+int mf_host_parse_buffer(const char *text, size_t len, mf_problem *p)
+{
+	memset(p, 0, sizeof *p);
+	const char *cur = text, *end = text + len;
+	int iters, feats, users, items, nnz;
+	double alpha;
+	if (!take_int(&cur, end, &iters) || !take_double(&cur, end, &alpha) || !take_int(&cur, end, &feats) ||
+	    !take_int(&cur, end, &users) || !take_int(&cur, end, &items) || !take_int(&cur, end, &nnz) || nnz < (1 << 16) ||
+	    (cur < end && !is_space(*cur)))
+		return parse_buffer_sequential(text, len, p);   /* small inputs and every irregular header */
+
+	int nthr = 1;
+#ifdef _OPENMP
+	nthr = omp_get_max_threads();
+#endif
+	if (nthr > 64) nthr = 64;
+	const size_t body = (size_t) (end - cur);
+	size_t start[65], count[65];
+	for (int t = 0; t <= nthr; t++) {
+		const char *s = cur + body * (size_t) t / (size_t) nthr;
+		if (t > 0 && t < nthr)
+			while (s < end && !is_space(*s)) ++s;   /* never cut a token */
+		start[t] = (size_t) (s - text);
+	}
+	start[nthr] = len;
+	#pragma omp parallel for schedule(static, 1) num_threads(nthr)
+	for (int t = 0; t < nthr; t++) {
+		size_t c = 0;
+		const char *s = text + start[t], *e = text + start[t + 1];
+		while (s < e) {
+			while (s < e && is_space(*s)) ++s;
+			if (s >= e) break;
+			++c;
+			while (s < e && !is_space(*s)) ++s;
+		}
+		count[t] = c;
+	}
+	size_t first[65];
+	first[0] = 0;
+	for (int t = 0; t < nthr; t++) first[t + 1] = first[t] + count[t];
+	const size_t need = 3 * (size_t) nnz;
+	if (first[nthr] < need) return parse_buffer_sequential(text, len, p);   /* too few tokens: exact error below */
+
+	mf_entry *ent = malloc(sizeof(mf_entry) * (size_t) nnz);
+	if (!ent) return MF_PARSE_NOMEM;
+	int bad = 0;
+	#pragma omp parallel for schedule(static, 1) num_threads(nthr) reduction(| : bad)
+	for (int t = 0; t < nthr; t++) {
+		size_t tok = first[t];
+		const char *s = text + start[t], *e = text + start[t + 1];
+		while (s < e && tok < need && !bad) {
+			while (s < e && is_space(*s)) ++s;
+			if (s >= e) break;
+			const char *b = s;
+			while (s < e && !is_space(*s)) ++s;
+			mf_entry *en = ent + tok / 3;
+			const int field = (int) (tok % 3);
+			if (field == 0)
+				bad |= !token_int(b, s, &en->row);
+			else if (field == 1)
+				bad |= !token_int(b, s, &en->col);
+			else
+				bad |= !token_double(b, s, &en->value);
+			++tok;
+		}
+	}
+	if (bad) {
+		free(ent);
+		return parse_buffer_sequential(text, len, p);
+	}
+	p->iters = iters;
+	p->alpha = alpha;
+	p->features = feats;
+	p->users = users;
+	p->items = items;
+	p->nnz = nnz;
+	p->entries = ent;
 	return MF_PARSE_OK;
 }
 

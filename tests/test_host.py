@@ -195,3 +195,43 @@ def test_bench_accounting_and_skewed_generator():
     assert lens.min() >= 20 and lens.max() > 3 * np.median(lens)          # power-law activity
     pop = np.bincount(col, minlength=200)
     assert pop.max() > 4 * np.median(pop)                                 # power-law popularity
+
+
+def test_parallel_parser_equals_sequential_semantics(capi, orc, tmp_path):
+    """Inputs large enough for the parallel body parser (>= 65536 entries): same entries as the reference
+    grammar gives, number forms included; irregular bodies fall back to the sequential parser and its errors."""
+    rng = np.random.default_rng(11)
+    n = 70000
+    row = np.sort(rng.integers(0, 5000, n)).astype(np.int32)
+    col = rng.integers(0, 4000, n).astype(np.int32)
+    val = rng.integers(1, 6, n).astype(np.float64)
+    forms = ["%d %d %.1f", "%d\t%d   %.6f", "%d %d %d", "%d %d %.3e"]
+    lines = ["7", "0.00025", "12", "5000 4000 %d" % n]
+    frac = rng.random(n)
+    vals = np.where(frac < 0.1, val + 0.123456789012, val)
+    for i in range(n):
+        if frac[i] < 0.1:
+            lines.append("%d %d %.12f" % (row[i], col[i], vals[i]))
+        else:
+            f = forms[i % len(forms)]
+            lines.append(f % (row[i], col[i], int(val[i])) if f.endswith("%d") else f % (row[i], col[i], val[i]))
+    text = "\n".join(lines) + "\n"
+    inst = capi.parse_text(text)
+    ref = orc.parse_in(text, is_text=True)
+    assert (inst.iters, inst.alpha, inst.feats, inst.users, inst.items, inst.nnz) == (7, 0.00025, 12, 5000, 4000, n)
+    assert np.array_equal(inst.row, ref.row) and np.array_equal(inst.col, ref.col)
+    assert np.array_equal(inst.val, ref.val)            # bit-equal to Python's correctly rounded float()
+    # one bad token deep inside the body: the sequential parser's error is what the caller sees
+    bad = text.replace("\n%d %d" % (row[40000], col[40000]), "\n%d x%d" % (row[40000], col[40000]), 1)
+    with pytest.raises(capi.ParseError) as e:
+        capi.parse_text(bad)
+    assert str(e.value) == "Error in non-zero entry."
+    # too few entries
+    with pytest.raises(capi.ParseError) as e:
+        capi.parse_text(text[: len(text) // 2])
+    assert str(e.value) == "Error in non-zero entry."
+    # fscanf splits "12.5" read with %d into 12 and .5 -- the fast path must not accept it as one token
+    odd = text.replace("\n%d %d " % (row[30000], col[30000]), "\n%d.5 %d " % (row[30000], col[30000]), 1)
+    with pytest.raises(capi.ParseError) as e:       # %d reads 12, the next %d meets ".5" and fails
+        capi.parse_text(odd)
+    assert str(e.value) == "Error in non-zero entry."
