@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(kWave) ordered_sum_kernel(OrderedSumArgs a)
 		auto issue = [&](int b) {
 			const char *g = src + (size_t) b * 1024;
 			const unsigned m0 = ring_base + (unsigned) (b & (kRing - 1)) * 1024u;
-			asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0) : "memory");
+			asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0) : "memory");   // m0 is a reserved register: hipcc re-loads it before each of its own uses
 		};
 		auto add_block = [&](int b, int entries) {
 			const char *slot = my + (b & (kRing - 1)) * 1024;
