@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(kWave) sweep_kernel(SweepArgs a)
 			// ---- phase A: lane n -> e_n (all lanes run it; lanes >= cnt produce unused garbage)
 			double e;
 			{
-				const double *t = tile + lane * stride;
+				const double *t = tile + (lane < nch ? lane : 0) * stride;   // lanes beyond the tile re-read row 0
 				double dot = 0.0;
 #pragma unroll 8
 				for (int k = 0; k < K; ++k)
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 			// ---- phase A
 			double e;
 			{
-				const double2 *t2 = reinterpret_cast<const double2 *>(tile + lane * S);
+				const double2 *t2 = reinterpret_cast<const double2 *>(tile + (lane < nch ? lane : 0) * S);   // lanes beyond the tile re-read row 0
 				double dot = 0.0;
 				if (KT > 0) {
 #pragma unroll
@@ -669,7 +669,7 @@ __global__ void __launch_bounds__(kCoopWaves *kWave) sweep_coop_kernel(SweepArgs
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 					double e;
 					{
-						const double2 *t2 = reinterpret_cast<const double2 *>(tile + lane * S);
+						const double2 *t2 = reinterpret_cast<const double2 *>(tile + (lane < nch ? lane : 0) * S);   // lanes beyond the tile re-read row 0
 						double dot = 0.0;
 #pragma unroll
 						for (int q = 0; q < P; ++q) {
