@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--partition", default="entries", choices=["entries", "rows"])
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong (default): the SAME instance is cut over the ranks, as BASELINE.json's config says; "
+                         "weak: users (and entries) grow with the rank count, items and K fixed")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo only to rehearse several ranks on ONE GPU")
     ap.add_argument("--skew", action="store_true",
@@ -165,6 +168,8 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    if args.scaling == "weak":
+        cfg["users"] *= world
     U, I, K = cfg["users"], cfg["items"], cfg["feats"]
     # ---- this rank's block of the synthetic instance
     t_setup = time.time()
@@ -246,7 +251,7 @@ def main():
     out = {
         "metric": "nnz_updates_per_sec", "value": total_nnz * args.steps / elapsed, "unit": "nnz-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": ("%s: synthetic %dx%d, K=%d, nnz=%d, alpha=%g, " % (args.config, U, I, K, total_nnz, cfg["alpha"]))
                                + ("power-law rows and item popularity" if args.skew else
                                   "rows %d..%d entries, uniform columns" % (cfg["min_row"], cfg["max_row"])),
