@@ -504,3 +504,20 @@ def test_randomised_shapes_all_paths_bit_exact(capi, orc, monkeypatch):
         Lo, Ro, bo = _oracle_run(orc, d)
         assert np.array_equal(L, Lo) and np.array_equal(R, Ro), (case, u, i, k, dens, iters)
         assert np.array_equal(best, bo), (case, u, i, k)
+
+
+@pytest.mark.parametrize("u,i,k", [(0, 5, 3), (4, 0, 3), (0, 0, 2), (3, 4, 1), (1, 1, 2)])
+def test_degenerate_shapes(capi, orc, u, i, k):
+    """No users, no items, nothing at all, K = 1: the C ABI must neither crash nor invent recommendations."""
+    d = dict(iters=3, alpha=0.01, feats=k, users=u, items=i, row=np.zeros(0, np.int32), col=np.zeros(0, np.int32),
+             val=np.zeros(0))
+    if u and i:
+        d = random_instance(u * 7 + i, u, i, k, density=0.5, iters=3)
+    L, R = capi.init_factors(u, i, k)
+    best = capi.backend_run(_inst(capi, d), L, R)
+    Lo, Ro, bo = _oracle_run(orc, d)
+    assert np.array_equal(L, Lo) and np.array_equal(R, Ro) and np.array_equal(best, bo)
+    if u >= 2:
+        L2, R2 = capi.init_factors(u, i, k)
+        best2 = capi.backend_run_multi(_inst(capi, d), L2, R2, [0, 0])
+        assert np.allclose(L2, Lo, rtol=1e-9, atol=1e-13) and np.array_equal(best2, bo)
