@@ -672,8 +672,24 @@ int mf_plan_create(mf_plan **out, const mf_shard *s)
 					}
 					continue;
 				}
+				// the scratch buffer holds K doubles per entry of every extreme row: keep it under a quarter of the free
+				// memory by raising the threshold (on Netflix-like data most entries sit in long columns)
+				size_t free_b = 0, total_b = 0;
+				(void) hipMemGetInfo(&free_b, &total_b);
+				const size_t cap_entries = std::max<size_t>(free_b / 4 / ((size_t) ((p->K + 15) / 16) * 128), 1);
+				int t_eff = t_kind;
+				for (;;) {
+					size_t ent = 0;
+					for (int r = 0; r < nrows; ++r) {
+						const int len = pt[(size_t) r + 1] - pt[r];
+						if (len >= t_eff) ent += (size_t) len;
+					}
+					if (ent <= cap_entries || t_eff > (1 << 29)) break;
+					t_eff *= 2;
+				}
+				if (p->max_row_len[kind] < t_eff) continue;
 				std::vector<int> lg, sh;
-				for (int r = 0; r < nrows; ++r) (pt[(size_t) r + 1] - pt[r] >= t_kind ? lg : sh).push_back(r);
+				for (int r = 0; r < nrows; ++r) (pt[(size_t) r + 1] - pt[r] >= t_eff ? lg : sh).push_back(r);
 				MF_TRY(dev_alloc(&p->long_rows[kind], lg.size()));
 				MF_TRY(dev_alloc(&p->short_rows[kind], sh.size()));
 				MF_TRY_HIP(hipMemcpy(p->long_rows[kind], lg.data(), lg.size() * sizeof(int), hipMemcpyHostToDevice));
