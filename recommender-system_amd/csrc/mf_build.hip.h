@@ -1,0 +1,370 @@
+// mf_build.hip.h -- CSR/CSC construction (device-side stable radix sort, host fallback) and the row schedule.
+#pragma once
+
+namespace {
+
+// inside helpers that return a status directly
+#define MF_TRY(x)                       \
+	do {                                \
+		int _rc = (x);                  \
+		if (_rc != MF_OK) return _rc;   \
+	} while (0)
+#define MF_TRY_HIP(call) MF_HIP(call)
+
+template <typename T>
+int dev_alloc(T **out, size_t count)
+{
+	*out = nullptr;
+	MF_HIP(hipMalloc((void **) out, std::max<size_t>(count, 1) * sizeof(T)));
+	return MF_OK;
+}
+
+// stable counting sort of the entries by `key` into (ptr, idx, val)
+void bucket(int64_t nnz, int nkeys, const int32_t *key, int32_t key_off, const int32_t *other,
+            int32_t other_off, const double *val, std::vector<int> &ptr, std::vector<int> &idx,
+            std::vector<double> &v)
+{
+	ptr.assign((size_t) nkeys + 1, 0);
+	for (int64_t n = 0; n < nnz; ++n) ptr[(size_t) (key[n] - key_off) + 1]++;
+	for (int k = 0; k < nkeys; ++k) ptr[(size_t) k + 1] += ptr[k];
+	std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+	idx.resize((size_t) nnz);
+	v.resize((size_t) nnz);
+	for (int64_t n = 0; n < nnz; ++n) {
+		const int pos = fill[(size_t) (key[n] - key_off)]++;
+		idx[(size_t) pos] = other[n] - other_off;
+		v[(size_t) pos] = val[n];
+	}
+}
+
+
+// ---- device-side CSR / CSC build: the entries are uploaded once in file order; a STABLE radix
+// sort of a permutation by row (CSR) or by column (CSC) keeps the file order inside every row and column,
+// which is what makes the sweeps reproduce the serial summation order.
+__global__ void __launch_bounds__(256) prep_keys_kernel(const int *__restrict__ row, const int *__restrict__ col,
+                                                        int64_t nnz, int u0, int uc, int items,
+                                                        unsigned *__restrict__ rkey, unsigned *__restrict__ perm,
+                                                        int *__restrict__ flags)
+{
+	const int64_t n = (int64_t) blockIdx.x * 256 + threadIdx.x;
+	if (n >= nnz) return;
+	const int r = row[n] - u0, c = col[n];
+	if (r < 0 || r >= uc || c < 0 || c >= items) atomicOr(&flags[0], 1);         // out of range
+	if (n > 0 && row[n - 1] > row[n]) atomicOr(&flags[1], 1);                      // not row-sorted
+	rkey[n] = (unsigned) r;
+	perm[n] = (unsigned) n;
+}
+
+__global__ void __launch_bounds__(256) gather_kernel(const unsigned *__restrict__ perm, int64_t nnz,
+                                                     const int *__restrict__ other, int other_off,
+                                                     const double *__restrict__ val, int *__restrict__ idx_out,
+                                                     double *__restrict__ val_out)
+{
+	const int64_t n = (int64_t) blockIdx.x * 256 + threadIdx.x;
+	if (n >= nnz) return;
+	const unsigned s = perm[n];
+	idx_out[n] = other[s] - other_off;
+	val_out[n] = val[s];
+}
+
+// ptr[k] = first position whose (sorted) key is >= k, k = 0..nkeys
+__global__ void __launch_bounds__(256) ptr_kernel(const unsigned *__restrict__ sorted, int64_t nnz, int nkeys,
+                                                  int *__restrict__ ptr)
+{
+	const int k = blockIdx.x * 256 + threadIdx.x;
+	if (k > nkeys) return;
+	int64_t lo = 0, hi = nnz;
+	while (lo < hi) {
+		const int64_t mid = (lo + hi) >> 1;
+		if (sorted[mid] < (unsigned) k) lo = mid + 1; else hi = mid;
+	}
+	ptr[k] = (int) lo;
+}
+
+__global__ void __launch_bounds__(256) copy_keys_kernel(const int *__restrict__ src, int64_t nnz,
+                                                        unsigned *__restrict__ key, unsigned *__restrict__ perm)
+{
+	const int64_t n = (int64_t) blockIdx.x * 256 + threadIdx.x;
+	if (n >= nnz) return;
+	key[n] = (unsigned) src[n];
+	perm[n] = (unsigned) n;
+}
+
+int bits_for(int nkeys)
+{
+	int b = 1;
+	while (b < 32 && (1ll << b) < (long long) nkeys) ++b;
+	return b;
+}
+
+struct DevTmp {   // frees its buffers on scope exit
+	std::vector<void *> bufs;
+	~DevTmp() { for (void *b : bufs) (void) hipFree(b); }
+	template <typename T> int get(T **out, size_t count)
+	{
+		const int rc = dev_alloc(out, count);
+		if (rc == MF_OK) bufs.push_back(*out);
+		return rc;
+	}
+};
+
+// Builds csr_* and csc_* of plan p from host SoA entries.  Returns MF_ERR_ARGUMENT for out-of-range indices.
+int build_on_device(mf_plan *p, const mf_shard *s, std::vector<int> &csr_ptr_host, std::vector<int> &csc_ptr_host)
+{
+	const int64_t nnz = s->nnz;
+	const size_t nz = (size_t) nnz;
+	hipStream_t st = p->stream;
+	MF_HIP(dev_alloc(&p->csr_ptr, (size_t) p->uc + 1) == MF_OK ? hipSuccess : hipErrorOutOfMemory);
+	MF_HIP(dev_alloc(&p->csc_ptr, (size_t) p->items + 1) == MF_OK ? hipSuccess : hipErrorOutOfMemory);
+	MF_HIP(dev_alloc(&p->csr_idx, nz + 64) == MF_OK ? hipSuccess : hipErrorOutOfMemory);
+	MF_HIP(dev_alloc(&p->csr_val, nz + 64) == MF_OK ? hipSuccess : hipErrorOutOfMemory);
+	MF_HIP(dev_alloc(&p->csc_idx, nz + 64) == MF_OK ? hipSuccess : hipErrorOutOfMemory);
+	MF_HIP(dev_alloc(&p->csc_val, nz + 64) == MF_OK ? hipSuccess : hipErrorOutOfMemory);
+	csr_ptr_host.assign((size_t) p->uc + 1, 0);
+	csc_ptr_host.assign((size_t) p->items + 1, 0);
+	if (nnz == 0) {
+		MF_HIP(hipMemsetAsync(p->csr_ptr, 0, ((size_t) p->uc + 1) * sizeof(int), st));
+		MF_HIP(hipMemsetAsync(p->csc_ptr, 0, ((size_t) p->items + 1) * sizeof(int), st));
+		MF_HIP(hipStreamSynchronize(st));
+		return MF_OK;
+	}
+	DevTmp tmp;
+	int *d_row = nullptr, *d_col = nullptr, *d_flags = nullptr;
+	unsigned *key_in = nullptr, *key_out = nullptr, *perm_in = nullptr, *perm_out = nullptr;
+	int rc;
+	if ((rc = tmp.get(&d_row, nz)) != MF_OK || (rc = tmp.get(&d_col, nz)) != MF_OK ||
+	    (rc = tmp.get(&key_in, nz)) != MF_OK || (rc = tmp.get(&key_out, nz)) != MF_OK ||
+	    (rc = tmp.get(&perm_in, nz)) != MF_OK || (rc = tmp.get(&perm_out, nz)) != MF_OK ||
+	    (rc = tmp.get(&d_flags, 2)) != MF_OK)
+		return rc;
+	// the values land directly in csr_val when the input is row-sorted (the usual case); otherwise csc_val is
+	// used as the staging copy of the file-order values and overwritten last
+	double *d_val = p->csc_val;
+	MF_HIP(hipMemcpyAsync(d_row, s->row, nz * sizeof(int), hipMemcpyHostToDevice, st));
+	MF_HIP(hipMemcpyAsync(d_col, s->col, nz * sizeof(int), hipMemcpyHostToDevice, st));
+	MF_HIP(hipMemcpyAsync(p->csr_val, s->val, nz * sizeof(double), hipMemcpyHostToDevice, st));
+	MF_HIP(hipMemsetAsync(d_flags, 0, 2 * sizeof(int), st));
+	const unsigned grid = (unsigned) ((nnz + 255) / 256);
+	hipLaunchKernelGGL(prep_keys_kernel, dim3(grid), dim3(256), 0, st, d_row, d_col, nnz, p->u0, p->uc, p->items,
+	                   key_in, perm_in, d_flags);
+	int flags[2] = {0, 0};
+	MF_HIP(hipMemcpyAsync(flags, d_flags, sizeof flags, hipMemcpyDeviceToHost, st));
+	MF_HIP(hipStreamSynchronize(st));
+	if (flags[0]) return MF_ERR_ARGUMENT;
+	const bool row_sorted = flags[1] == 0;
+
+	size_t temp_bytes = 0, need = 0;
+	MF_HIP(rocprim::radix_sort_pairs(nullptr, need, key_in, key_out, perm_in, perm_out, nz, 0, bits_for(p->uc), st));
+	temp_bytes = need;
+	MF_HIP(rocprim::radix_sort_pairs(nullptr, need, key_in, key_out, perm_in, perm_out, nz, 0, bits_for(p->items), st));
+	temp_bytes = std::max(temp_bytes, need);
+	void *d_temp = nullptr;
+	if ((rc = tmp.get((char **) &d_temp, temp_bytes)) != MF_OK) return rc;
+
+	const double *vals_file_order = p->csr_val;   // file-order values currently live here
+	if (row_sorted) {
+		// CSR == file order: idx = col, val = val (already in place), ptr from the row keys
+		MF_HIP(hipMemcpyAsync(p->csr_idx, d_col, nz * sizeof(int), hipMemcpyDeviceToDevice, st));
+		hipLaunchKernelGGL(ptr_kernel, dim3((unsigned) ((p->uc + 256) / 256)), dim3(256), 0, st, key_in, nnz, p->uc,
+		                   p->csr_ptr);
+	} else {
+		// keep a file-order copy of the values, then permute into csr_val
+		MF_HIP(hipMemcpyAsync(d_val, p->csr_val, nz * sizeof(double), hipMemcpyDeviceToDevice, st));
+		vals_file_order = d_val;
+		MF_HIP(rocprim::radix_sort_pairs(d_temp, temp_bytes, key_in, key_out, perm_in, perm_out, nz, 0,
+		                                 bits_for(p->uc), st));
+		hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(256), 0, st, perm_out, nnz, d_col, 0, vals_file_order,
+		                   p->csr_idx, p->csr_val);
+		hipLaunchKernelGGL(ptr_kernel, dim3((unsigned) ((p->uc + 256) / 256)), dim3(256), 0, st, key_out, nnz, p->uc,
+		                   p->csr_ptr);
+	}
+	// CSC: stable sort of the file order by column
+	hipLaunchKernelGGL(copy_keys_kernel, dim3(grid), dim3(256), 0, st, d_col, nnz, key_in, perm_in);
+	MF_HIP(rocprim::radix_sort_pairs(d_temp, temp_bytes, key_in, key_out, perm_in, perm_out, nz, 0,
+	                                 bits_for(p->items), st));
+	if (row_sorted) {
+		hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(256), 0, st, perm_out, nnz, d_row, p->u0, vals_file_order,
+		                   p->csc_idx, p->csc_val);
+	} else {
+		// vals_file_order aliases csc_val: gather into a temporary, then copy
+		double *d_val2 = nullptr;
+		if ((rc = tmp.get(&d_val2, nz)) != MF_OK) return rc;
+		hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(256), 0, st, perm_out, nnz, d_row, p->u0, vals_file_order,
+		                   p->csc_idx, d_val2);
+		MF_HIP(hipMemcpyAsync(p->csc_val, d_val2, nz * sizeof(double), hipMemcpyDeviceToDevice, st));
+	}
+	hipLaunchKernelGGL(ptr_kernel, dim3((unsigned) ((p->items + 256) / 256)), dim3(256), 0, st, key_out, nnz, p->items,
+	                   p->csc_ptr);
+	MF_HIP(hipGetLastError());
+	MF_HIP(hipMemcpyAsync(csr_ptr_host.data(), p->csr_ptr, ((size_t) p->uc + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+	MF_HIP(hipMemcpyAsync(csc_ptr_host.data(), p->csc_ptr, ((size_t) p->items + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+	MF_HIP(hipStreamSynchronize(st));
+	return MF_OK;
+}
+
+
+// CSR over the shard's users and CSC over the items, on the device (default) or bucketed on the host
+// (MF_BUILD=host, kept for A/B tests); rptr / cptr return the two row-pointer arrays for the schedule decisions.
+int build_sparse(mf_plan *p, const mf_shard *s, std::vector<int> &rptr, std::vector<int> &cptr)
+{
+	const char *where = getenv("MF_BUILD");
+	if (where && strcmp(where, "host") == 0) {
+		for (int64_t n = 0; n < s->nnz; ++n)
+			if (s->row[n] < s->user_begin || s->row[n] >= s->user_begin + s->user_count || s->col[n] < 0 ||
+			    s->col[n] >= s->items)
+				return MF_ERR_ARGUMENT;
+		std::vector<int> idx;
+		std::vector<double> val;
+		const size_t nz = (size_t) s->nnz;
+		try {
+			bucket(s->nnz, p->uc, s->row, p->u0, s->col, 0, s->val, rptr, idx, val);
+		} catch (const std::bad_alloc &) {
+			return MF_ERR_NO_MEMORY;
+		}
+		MF_TRY(dev_alloc(&p->csr_ptr, (size_t) p->uc + 1));
+		MF_TRY(dev_alloc(&p->csr_idx, nz + 64));
+		MF_TRY(dev_alloc(&p->csr_val, nz + 64));
+		MF_TRY_HIP(hipMemcpy(p->csr_ptr, rptr.data(), ((size_t) p->uc + 1) * sizeof(int), hipMemcpyHostToDevice));
+		if (nz) {
+			MF_TRY_HIP(hipMemcpy(p->csr_idx, idx.data(), nz * sizeof(int), hipMemcpyHostToDevice));
+			MF_TRY_HIP(hipMemcpy(p->csr_val, val.data(), nz * sizeof(double), hipMemcpyHostToDevice));
+		}
+		try {
+			bucket(s->nnz, p->items, s->col, 0, s->row, p->u0, s->val, cptr, idx, val);
+		} catch (const std::bad_alloc &) {
+			return MF_ERR_NO_MEMORY;
+		}
+		MF_TRY(dev_alloc(&p->csc_ptr, (size_t) p->items + 1));
+		MF_TRY(dev_alloc(&p->csc_idx, nz + 64));
+		MF_TRY(dev_alloc(&p->csc_val, nz + 64));
+		MF_TRY_HIP(hipMemcpy(p->csc_ptr, cptr.data(), ((size_t) p->items + 1) * sizeof(int), hipMemcpyHostToDevice));
+		if (nz) {
+			MF_TRY_HIP(hipMemcpy(p->csc_idx, idx.data(), nz * sizeof(int), hipMemcpyHostToDevice));
+			MF_TRY_HIP(hipMemcpy(p->csc_val, val.data(), nz * sizeof(double), hipMemcpyHostToDevice));
+		}
+	} else {
+		MF_TRY(build_on_device(p, s, rptr, cptr));
+	}
+	return MF_OK;
+}
+
+// Schedule of the two sweeps from the row lengths: which rows count as long, whether a tiny sweep runs as ONE
+// cooperative launch, and the segment tables + scratch buffer of the extreme-row path.
+int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vector<int> &cptr)
+{
+	for (int u = 0; u < p->uc; ++u) p->max_row_len[1] = std::max(p->max_row_len[1], rptr[(size_t) u + 1] - rptr[u]);
+	for (int j = 0; j < p->items; ++j) p->max_row_len[0] = std::max(p->max_row_len[0], cptr[(size_t) j + 1] - cptr[j]);
+	// ---- long / short row lists.  A row is "long" when its serial walk (~0.075 us per entry at 16-entry
+	// chunks) would exceed roughly a quarter of the bandwidth time of the whole sweep (nnz * 8K bytes at
+	// ~7 TB/s): len > 4e-6 * nnz * K, and never below 128 entries.  cfg4 has none; a power-law instance a few.
+	const char *skew_env = getenv("MF_SWEEP_SKEW");   // "0" disables the split
+	if (p->sweep.prod && !(skew_env && skew_env[0] == '0')) {
+		const size_t per_entry = 2 * (size_t) mf::kCoopProducers * (size_t) p->sweep.row_bytes;
+		const size_t head = (size_t) p->sweep.xs_bytes;
+		int nl = (int) std::min<size_t>(32, (kLdsPerCu - 4096 - head) / per_entry);
+		if (const char *env = getenv("MF_SWEEP_NCH")) {
+			const int v = atoi(env);
+			if (v >= 1 && v <= 64 && head + (size_t) v * per_entry <= kLdsPerCu) nl = v;
+		}
+		double thr = 4e-6 * (double) p->nnz * (double) p->K;
+		if (const char *t = getenv("MF_SWEEP_LONG")) thr = atof(t);
+		const int t_long = std::max(128, (int) std::min(thr, 2e9));
+		// estimated bandwidth time of one sweep; below ~50 us the two-stream fork/join (tens of us on the 6000
+		// launches of ML100k) costs more than the split saves: use one cooperative launch for all rows there
+		const double est_us = (double) p->nnz * 8.0 * p->K / 6e12 * 1e6;
+		const int nc = (int) std::min<size_t>(32, (48 * 1024) / per_entry);
+		long long scratch_entries = 0;
+		(void) nl;
+		for (int kind = 0; kind < 2; ++kind) {
+			const std::vector<int> &pt = kind == 0 ? cptr : rptr;
+			const int nrows = kind == 0 ? p->items : p->uc;
+			// ... and only rows well above the average count as long: when every row is equally long (the cfg4
+			// twin: 1000 items x 1000 entries) there is no skew to fix and the single-wave kernel is the faster one
+			const int t_kind = getenv("MF_SWEEP_LONG") ? t_long : std::max(t_long, (int) std::min<long long>(4 * (long long) (p->nnz / std::max(nrows, 1)), 2000000000ll));
+			if (p->max_row_len[kind] < t_kind) continue;
+			if (est_us < 50.0 && nrows < 4096 && !getenv("MF_SWEEP_LONG")) {
+				if (p->sweep.coop && (nc >= 8 || getenv("MF_SWEEP_NCH"))) {
+					p->coop_all[kind] = true;
+					p->nch_coop = getenv("MF_SWEEP_NCH") ? nl : nc;
+					p->lds_bytes_coop = head + (size_t) p->nch_coop * per_entry;
+				}
+				continue;
+			}
+			// the scratch buffer holds K doubles per entry of every extreme row: keep it under a quarter of the free
+			// memory by raising the threshold (on Netflix-like data most entries sit in long columns)
+			size_t free_b = 0, total_b = 0;
+			(void) hipMemGetInfo(&free_b, &total_b);
+			const size_t cap_entries = std::max<size_t>(free_b / 4 / ((size_t) ((p->K + 15) / 16) * 128), 1);
+			int t_eff = t_kind;
+			for (;;) {
+				size_t ent = 0;
+				for (int r = 0; r < nrows; ++r) {
+					const int len = pt[(size_t) r + 1] - pt[r];
+					if (len >= t_eff) ent += (size_t) len;
+				}
+				if (ent <= cap_entries || t_eff > (1 << 29)) break;
+				t_eff *= 2;
+			}
+			if (p->max_row_len[kind] < t_eff) continue;
+			std::vector<int> lg, sh;
+			for (int r = 0; r < nrows; ++r) (pt[(size_t) r + 1] - pt[r] >= t_eff ? lg : sh).push_back(r);
+			MF_TRY(dev_alloc(&p->long_rows[kind], lg.size()));
+			MF_TRY(dev_alloc(&p->short_rows[kind], sh.size()));
+			MF_TRY_HIP(hipMemcpy(p->long_rows[kind], lg.data(), lg.size() * sizeof(int), hipMemcpyHostToDevice));
+			if (!sh.empty())
+				MF_TRY_HIP(hipMemcpy(p->short_rows[kind], sh.data(), sh.size() * sizeof(int), hipMemcpyHostToDevice));
+			p->n_long[kind] = (int) lg.size();
+			p->n_short[kind] = (int) sh.size();
+			// segments of 256 entries; scratch offsets in entry units, rows back to back
+			constexpr int kSeg = 256;
+			std::vector<int> srow, sbeg, send, lcnt;
+			std::vector<long long> sout, lbeg;
+			long long off = 0;
+			for (int r : lg) {
+				const int b = pt[r], e = pt[(size_t) r + 1];
+				lbeg.push_back(off);
+				lcnt.push_back(e - b);
+				for (int c = b; c < e; c += kSeg) {
+					srow.push_back(r);
+					sbeg.push_back(c);
+					send.push_back(std::min(e, c + kSeg));
+					sout.push_back(off + (c - b));
+				}
+				off += e - b;
+			}
+			scratch_entries = std::max(scratch_entries, off);
+			p->n_seg[kind] = (int) srow.size();
+			MF_TRY(dev_alloc(&p->seg_row[kind], srow.size()));
+			MF_TRY(dev_alloc(&p->seg_beg[kind], srow.size()));
+			MF_TRY(dev_alloc(&p->seg_end[kind], srow.size()));
+			MF_TRY(dev_alloc(&p->seg_out[kind], srow.size()));
+			MF_TRY(dev_alloc(&p->lr_sbeg[kind], lg.size()));
+			MF_TRY(dev_alloc(&p->lr_cnt[kind], lg.size()));
+			MF_TRY_HIP(hipMemcpy(p->seg_row[kind], srow.data(), srow.size() * sizeof(int), hipMemcpyHostToDevice));
+			MF_TRY_HIP(hipMemcpy(p->seg_beg[kind], sbeg.data(), srow.size() * sizeof(int), hipMemcpyHostToDevice));
+			MF_TRY_HIP(hipMemcpy(p->seg_end[kind], send.data(), srow.size() * sizeof(int), hipMemcpyHostToDevice));
+			MF_TRY_HIP(hipMemcpy(p->seg_out[kind], sout.data(), srow.size() * sizeof(long long), hipMemcpyHostToDevice));
+			MF_TRY_HIP(hipMemcpy(p->lr_sbeg[kind], lbeg.data(), lg.size() * sizeof(long long), hipMemcpyHostToDevice));
+			MF_TRY_HIP(hipMemcpy(p->lr_cnt[kind], lcnt.data(), lg.size() * sizeof(int), hipMemcpyHostToDevice));
+		}
+		if (p->coop_all[0] || p->coop_all[1])
+			MF_TRY_HIP(hipFuncSetAttribute((const void *) p->sweep.coop, hipFuncAttributeMaxDynamicSharedMemorySize,
+			                               (int) p->lds_bytes_coop));
+		if (p->n_long[0] || p->n_long[1]) {
+			MF_TRY_HIP(hipFuncSetAttribute((const void *) p->sweep.prod, hipFuncAttributeMaxDynamicSharedMemorySize,
+			                               (int) p->lds_bytes));
+			// [16-column slice][entry][16 doubles]; 8 entries of padding per slice: the last block of a row is read whole
+			p->scratch_entries = (size_t) scratch_entries + 8;
+			MF_TRY(dev_alloc(&p->scratch, p->scratch_entries * 16 * (size_t) ((p->K + 15) / 16)));
+			MF_TRY_HIP(hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking));
+			MF_TRY_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+			MF_TRY_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+		}
+	}
+	return MF_OK;
+}
+
+#undef MF_TRY
+#undef MF_TRY_HIP
+
+}  // namespace

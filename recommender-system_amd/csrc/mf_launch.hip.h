@@ -1,0 +1,180 @@
+// mf_launch.hip.h -- choice of the sweep kernel variant / chunk size and the launch of one sweep.
+#pragma once
+
+namespace {
+
+int choose_sweep(mf_plan *p)
+{
+	const int K = p->K;
+	p->sweep = SweepVariant{nullptr, 0, 0, 0, 0, 0, nullptr, nullptr};
+	const char *impl = getenv("MF_SWEEP_IMPL");   // "dma" (default) | "reg": register-staged form only
+	const bool allow_dma = !(impl && strcmp(impl, "reg") == 0);
+	if (allow_dma)
+		for (const auto &v : kDma)
+			if (v.kt == K) p->sweep = v;
+	if (!p->sweep.fn && allow_dma && (K & 1) == 0)
+		for (const auto &v : kDmaGeneric)
+			if (K <= 128 * v.kpmax && !p->sweep.fn) {
+				p->sweep = v;
+				p->sweep.row_bytes = 16 * ((K / 2) | 1);
+				p->sweep.xs_bytes = ((K * 8 + 255) / 256) * 256;
+			}
+	if (!p->sweep.fn)
+		for (const auto &v : kSpecialised)
+			if (v.kt == K) p->sweep = v;
+	if (!p->sweep.fn)
+		for (const auto &v : kGeneric)
+			if (K <= v.kpmax * mf::kWave) {
+				p->sweep = v;
+				break;
+			}
+	if (!p->sweep.fn) return MF_ERR_UNSUPPORTED;
+
+	p->stride = K | 1;
+	const size_t row_bytes = p->sweep.dma ? (size_t) p->sweep.row_bytes : (size_t) p->stride * sizeof(double);
+	const size_t head = p->sweep.dma ? (size_t) p->sweep.xs_bytes : 0;
+	auto fit = [&](size_t budget) {
+		return budget > head ? (int) std::min<size_t>(64, (budget - head) / row_bytes) : 0;
+	};
+	// Chunk size = latency hiding vs fixed cost.  Each single-wave workgroup alternates "gather a chunk"
+	// and "compute on it", so the bytes in flight per CU come from OTHER resident workgroups: small tiles
+	// (~13 KB -> ~11 workgroups per CU) beat big ones (measured on cfg4, K=100: nch 64/32/16/8 ->
+	// 37.1/29.3/24.1/25.5 ms per iteration); phase A costs K steps per chunk whatever its size, which is
+	// what stops the trend below ~12 entries.
+	// K=256: nch 8/12/16/24 -> 71/66/78/82 ms (12 rows = 6 workgroups per CU); K=30: nch 16..32 best.
+	int nch = 16;
+	if (head + (size_t) nch * row_bytes > kLdsPerCu / 6) nch = std::max(12, fit(kLdsPerCu / 6));
+	nch = std::min(nch, fit(kLdsPerCu));
+	if (const char *env = getenv("MF_SWEEP_NCH")) {
+		const int v = atoi(env);
+		if (v >= 1 && v <= 64 && head + (size_t) v * row_bytes <= kLdsPerCu) nch = v;
+	}
+	if (nch < 1) return MF_ERR_UNSUPPORTED;
+	p->nch = nch;
+	p->lds_bytes = head + (size_t) nch * row_bytes;
+	// A sweep over FEW rows (ML100k: 943 x 1682) cannot fill 256 CUs whatever the chunk size; its time is the
+	// longest row's serial chain of chunks, so use the largest chunk there (737 entries: 47 -> 12 chunks).
+	int few = std::max(nch, std::min(64, fit(kLdsPerCu / 2)));
+	if (getenv("MF_SWEEP_NCH")) few = nch;
+	p->nch_few = few;
+	p->lds_bytes_few = head + (size_t) few * row_bytes;
+	MF_HIP(hipFuncSetAttribute((const void *) p->sweep.fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+	                           (int) std::max(p->lds_bytes, p->lds_bytes_few)));
+	return MF_OK;
+}
+
+
+int launch_sweep(mf_plan *p, int kind, int seed)
+{
+	mf::SweepArgs a;
+	a.K = p->K;
+	a.nch = p->nch;
+	a.stride = p->stride;
+	a.seed = seed;
+	a.c2 = p->alpha * 2;
+	const int nxt = p->cur ^ 1;
+	if (kind == 0) {   // item sweep: X = R, Y = L, CSC
+		a.nrows = p->items;
+		a.ptr = p->csc_ptr;
+		a.idx = p->csc_idx;
+		a.val = p->csc_val;
+		a.X_old = p->Rbuf[p->cur];
+		a.Y_old = p->Lbuf[p->cur];
+		a.X_new = p->Rbuf[nxt];
+	} else {           // user sweep: X = L, Y = R, CSR
+		a.nrows = p->uc;
+		a.ptr = p->csr_ptr;
+		a.idx = p->csr_idx;
+		a.val = p->csr_val;
+		a.X_old = p->Lbuf[p->cur];
+		a.Y_old = p->Rbuf[p->cur];
+		a.X_new = p->Lbuf[nxt];
+	}
+	a.rowlist = nullptr;
+	a.seg_row = a.seg_beg = a.seg_end = nullptr;
+	a.seg_out = nullptr;
+	a.scratch = nullptr;
+	a.scratch_entries = 0;
+	if (a.nrows <= 0) return MF_OK;
+	const bool few_rows = a.nrows < 4096;
+	const bool coop = p->coop_all[kind];
+	if (few_rows) a.nch = coop ? p->nch_coop : p->nch_few;
+	const size_t lds = coop ? p->lds_bytes_coop : (few_rows ? p->lds_bytes_few : p->lds_bytes);
+	const SweepFn fn = coop ? p->sweep.coop : p->sweep.fn;
+	const int block = coop ? mf::kCoopWaves * mf::kWave : mf::kWave;
+	const int grid = std::min(a.nrows, 1 << 20);
+	TimedLaunch t{};
+	if (p->timing) {
+		MF_HIP(hipEventCreate(&t.t0));
+		MF_HIP(hipEventCreate(&t.t1));
+		t.kind = kind;
+		MF_HIP(hipEventRecord(t.t0, p->stream));
+	}
+	void *args[] = {&a};
+	if (p->n_long[kind] > 0) {
+		// extreme rows on the side stream, concurrently with the other rows on the main stream:
+		//   products kernel over their 256-entry segments -> ordered sum per (row, 16-column slice)
+		mf::SweepArgs b = a;
+		b.nrows = p->n_seg[kind];
+		b.rowlist = nullptr;
+		b.nch = p->nch;
+		b.seg_row = p->seg_row[kind];
+		b.seg_beg = p->seg_beg[kind];
+		b.seg_end = p->seg_end[kind];
+		b.seg_out = p->seg_out[kind];
+		b.scratch = p->scratch;
+		b.scratch_entries = p->scratch_entries;
+		void *bargs[] = {&b};
+		mf::OrderedSumArgs o;
+		o.nrows = p->n_long[kind];
+		o.K = p->K;
+		o.seed = seed;
+		o.nslices = (p->K + 15) / 16;
+		o.row = p->long_rows[kind];
+		o.sbeg = p->lr_sbeg[kind];
+		o.cnt = p->lr_cnt[kind];
+		o.scratch = p->scratch;
+		o.scratch_entries = p->scratch_entries;
+		o.X_old = a.X_old;
+		o.X_new = a.X_new;
+		void *oargs[] = {&o};
+		MF_HIP(hipEventRecord(p->ev_fork, p->stream));
+		MF_HIP(hipStreamWaitEvent(p->side_stream, p->ev_fork, 0));
+		MF_HIP(hipLaunchKernel((const void *) p->sweep.prod, dim3(b.nrows), dim3(mf::kWave), bargs, p->lds_bytes,
+		                       p->side_stream));
+		MF_HIP(hipLaunchKernel((const void *) mf::ordered_sum_kernel, dim3(o.nrows * o.nslices), dim3(mf::kWave), oargs,
+		                       0, p->side_stream));
+		MF_HIP(hipEventRecord(p->ev_join, p->side_stream));
+		a.nrows = p->n_short[kind];
+		a.rowlist = p->short_rows[kind];
+		a.nch = p->nch;   // the extreme rows are gone: the occupancy-friendly chunk size is right again
+		if (a.nrows > 0)
+			MF_HIP(hipLaunchKernel((const void *) p->sweep.fn, dim3(std::min(a.nrows, 1 << 20)), dim3(mf::kWave), args,
+			                       p->lds_bytes, p->stream));
+		MF_HIP(hipStreamWaitEvent(p->stream, p->ev_join, 0));
+	} else {
+		MF_HIP(hipLaunchKernel((const void *) fn, dim3(grid), dim3(block), args, lds, p->stream));
+	}
+	if (p->timing) {
+		MF_HIP(hipEventRecord(t.t1, p->stream));
+		p->timed.push_back(t);
+	}
+	return MF_OK;
+}
+
+int drain_timing(mf_plan *p)
+{
+	for (auto &t : p->timed) {
+		MF_HIP(hipEventSynchronize(t.t1));
+		float ms = 0.f;
+		MF_HIP(hipEventElapsedTime(&ms, t.t0, t.t1));
+		p->acc_launch[t.kind]++;
+		p->acc_ms[t.kind] += ms;
+		(void) hipEventDestroy(t.t0);
+		(void) hipEventDestroy(t.t1);
+	}
+	p->timed.clear();
+	return MF_OK;
+}
+
+}  // namespace

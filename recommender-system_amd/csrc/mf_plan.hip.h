@@ -1,0 +1,136 @@
+// mf_plan.hip.h -- error macro, kernel variant tables and the resident plan (struct mf_plan).
+#pragma once
+
+namespace {
+
+thread_local std::string g_last_hip_error;
+
+#define MF_HIP(call)                                                                        \
+	do {                                                                                    \
+		hipError_t _e = (call);                                                             \
+		if (_e != hipSuccess) {                                                             \
+			g_last_hip_error = std::string(#call) + ": " + hipGetErrorString(_e);           \
+			return _e == hipErrorOutOfMemory ? MF_ERR_NO_MEMORY : MF_ERR_HIP;               \
+		}                                                                                   \
+	} while (0)
+
+using SweepFn = void (*)(mf::SweepArgs);
+
+struct SweepVariant {
+	SweepFn fn;
+	int kt;         // compile-time K, 0 = runtime K
+	int kpmax;      // 64-column groups held in registers (register-staged form)
+	int dma;        // 1: LDS-DMA form
+	int row_bytes;  // LDS tile row stride in bytes (DMA form)
+	int xs_bytes;   // LDS bytes in front of the tile (DMA form)
+	SweepFn coop;   // row-cooperative form for tiny sweeps (compile-time-K DMA variants only)
+	SweepFn prod;   // products form for segments of extreme rows (all DMA variants)
+};
+
+template <int KT, int KP>
+constexpr SweepVariant variant()
+{
+	return SweepVariant{mf::sweep_kernel<KT, KP>, KT, KP, 0, 0, 0, nullptr, nullptr};
+}
+
+template <int KT>
+constexpr SweepVariant dma_variant()
+{
+	return SweepVariant{mf::sweep_dma_kernel<KT, mf::DmaGeom<KT>::kPasses>, KT, 0, 1, mf::DmaGeom<KT>::kStride,
+	                    mf::DmaGeom<KT>::kXsBytes, mf::sweep_coop_kernel<KT>,
+	                    mf::sweep_dma_kernel<KT, mf::DmaGeom<KT>::kPasses, true>};
+}
+
+// run-time even K <= 128 * NPASS through the LDS-DMA kernel (row_bytes / xs_bytes filled in per plan)
+template <int NPASS>
+constexpr SweepVariant dma_generic_variant()
+{
+	return SweepVariant{mf::sweep_dma_kernel<0, NPASS>, 0, NPASS, 1, 0, 0, nullptr, mf::sweep_dma_kernel<0, NPASS, true>};
+}
+
+// K-specialised instances for the K of the bundled samples and of the BASELINE configs, then generic ones.
+const SweepVariant kSpecialised[] = {
+    variant<10, 1>(), variant<20, 1>(), variant<30, 1>(), variant<50, 1>(),
+    variant<100, 2>(), variant<128, 2>(), variant<256, 4>(),
+};
+// LDS-DMA form: the production kernel for these (even) K
+const SweepVariant kDma[] = {
+    dma_variant<10>(), dma_variant<20>(), dma_variant<30>(), dma_variant<50>(),
+    dma_variant<100>(), dma_variant<128>(), dma_variant<256>(),
+};
+const SweepVariant kDmaGeneric[] = {
+    dma_generic_variant<1>(), dma_generic_variant<2>(), dma_generic_variant<4>(), dma_generic_variant<8>(),
+};
+const SweepVariant kGeneric[] = {
+    variant<0, 1>(), variant<0, 2>(), variant<0, 4>(), variant<0, 8>(),
+    variant<0, 16>(), variant<0, 32>(), variant<0, 64>(),
+};
+
+constexpr size_t kLdsPerCu = 160 * 1024;
+
+struct TimedLaunch {
+	hipEvent_t t0, t1;
+	int kind;   // 0 item sweep, 1 user sweep
+};
+
+}  // namespace
+
+struct mf_plan {
+	int device = 0;
+	int users_total = 0, items = 0, K = 0;
+	int u0 = 0, uc = 0;
+	int64_t nnz = 0;
+	double alpha = 0.0;
+	int flags = 0;
+
+	hipStream_t own_stream = nullptr;
+	hipStream_t stream = nullptr;
+
+	// CSR over the shard's users (idx = item id) and CSC over items (idx = LOCAL user id)
+	int *csr_ptr = nullptr, *csr_idx = nullptr;
+	double *csr_val = nullptr;
+	int *csc_ptr = nullptr, *csc_idx = nullptr;
+	double *csc_val = nullptr;
+
+	double *Lbuf[2] = {nullptr, nullptr};
+	double *Rbuf[2] = {nullptr, nullptr};
+	bool r_external = false;
+	int cur = 0;            // generation index of the current factors
+	bool have_factors = false;
+	int *best_dev = nullptr;
+	// MFMA recommend scratch
+	double *lnorm = nullptr;
+	unsigned long long *rmax_bits = nullptr;
+	int *ulist = nullptr, *ucount = nullptr;
+	int64_t last_uncertain = -1;   // users re-scored by the exact pass in the last recommend (-1: exact form ran)
+
+	SweepVariant sweep{};
+	int nch = 0, stride = 0;
+	size_t lds_bytes = 0;
+	int nch_few = 0;            // chunk size when a sweep has too few rows to fill the chip (see choose_sweep)
+	size_t lds_bytes_few = 0;
+	int max_row_len[2] = {0, 0}; // longest column (item sweep) / longest user row (user sweep)
+	// skew-aware split of a sweep with many rows: rows whose serial walk would dominate the launch go to the
+	// row-cooperative kernel on a side stream, the others stay on the single-wave kernel
+	int *long_rows[2] = {nullptr, nullptr}, *short_rows[2] = {nullptr, nullptr};
+	int n_long[2] = {0, 0}, n_short[2] = {0, 0};
+	// extreme rows of LARGE sweeps: 256-entry segments -> scaled rows in `scratch` -> ordered sum
+	int n_seg[2] = {0, 0};
+	int *seg_row[2] = {nullptr, nullptr}, *seg_beg[2] = {nullptr, nullptr}, *seg_end[2] = {nullptr, nullptr};
+	long long *seg_out[2] = {nullptr, nullptr}, *lr_sbeg[2] = {nullptr, nullptr};
+	int *lr_cnt[2] = {nullptr, nullptr};
+	double *scratch = nullptr;
+	size_t scratch_entries = 0;
+	// tiny sweeps (a few us of data): ONE cooperative launch over all rows; a fork/join costs more than it saves
+	int nch_coop = 0;
+	size_t lds_bytes_coop = 0;
+	bool coop_all[2] = {false, false};
+	hipStream_t side_stream = nullptr;
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+
+	bool timing = false;
+	std::vector<TimedLaunch> timed;
+	int64_t acc_launch[2] = {0, 0};
+	double acc_ms[2] = {0.0, 0.0};
+};
+

@@ -1,0 +1,478 @@
+// mf_recommend.hip.h -- the recommendation step: exact form, FP64-MFMA form with certification, row norms,
+// dense predictions for the debug dump.
+#pragma once
+#include "mf_common.hip.h"
+
+namespace mf {
+// ------------------------------------------------------------------------------------------------
+// Recommend kernel (exact form): fused L_blk * R^T with a masked running arg-max; B is never stored.
+// One 256-thread workgroup owns 64 users and walks all item tiles (64 items) in ascending order.
+// Each thread accumulates a 4x4 register block sequentially in k from 0.0 (mat2d.c:100-113 order), so
+// every score equals the reference's B[i][j] bit for bit.  Rated (i, j) are excluded by a per-user
+// cursor over the shard's CSR row (print_output's `aix`, matFact.c:13-23); ties keep the lower j.
+// ------------------------------------------------------------------------------------------------
+struct RecArgs {
+	int users;    // users in this shard
+	int items;
+	int K;
+	const double *__restrict__ L;    // users x K
+	const double *__restrict__ R;    // items x K
+	const int *__restrict__ csr_ptr; // users + 1
+	const int *__restrict__ csr_idx; // item ids, ascending within a user
+	int *__restrict__ best;          // users
+	const int *__restrict__ ulist;   // optional: only these users (indices into the shard), `users` = its length
+};
+
+struct Cand {
+	double bv;   // best non-NaN value so far
+	int bi;      // its index, -1 if none
+	int first;   // first unrated index, -1 if none
+	int fnan;    // that first unrated score is NaN
+};
+
+__device__ __forceinline__ void cand_insert(Cand &c, double s, int j)
+{
+	const bool nan = s != s;
+	if (c.first < 0) {
+		c.first = j;
+		c.fnan = nan;
+	}
+	if (!nan && (c.bi < 0 || s > c.bv)) {
+		c.bv = s;
+		c.bi = j;
+	}
+}
+
+// left = earlier items, right = later items
+__device__ __forceinline__ void cand_merge(Cand &l, const Cand &r)
+{
+	if (l.first < 0) {
+		l.first = r.first;
+		l.fnan = r.fnan;
+	}
+	if (r.bi >= 0 && (l.bi < 0 || r.bv > l.bv)) {
+		l.bv = r.bv;
+		l.bi = r.bi;
+	}
+}
+
+constexpr int kRT = 64;   // users per workgroup, items per tile
+constexpr int kRKC = 16;  // k chunk staged in LDS
+constexpr int kRLD = kRT + 2;
+
+__global__ void __launch_bounds__(256) recommend_kernel(RecArgs a)
+{
+	__shared__ double Ls[kRKC][kRLD];
+	__shared__ double Rs[kRKC][kRLD];
+	__shared__ unsigned long long maskw[kRT];
+
+	const int tid = threadIdx.x;
+	const int tx = tid & 15, ty = tid >> 4;
+	const int i0 = blockIdx.x * kRT;
+	const int K = a.K;
+
+	// cursor state of the mask walker (threads 0..63: one user each)
+	int cur = 0, cend = 0, nextcol = INT32_MAX;
+	if (tid < kRT && i0 + tid < a.users) {
+		const int uid = a.ulist ? a.ulist[i0 + tid] : i0 + tid;
+		cur = a.csr_ptr[uid];
+		cend = a.csr_ptr[uid + 1];
+		nextcol = cur < cend ? a.csr_idx[cur] : INT32_MAX;
+	}
+	// running result, kept by the tx == 0 lane of each 16-lane group for its 4 users
+	Cand run[4];
+#pragma unroll
+	for (int u = 0; u < 4; ++u) run[u] = Cand{0.0, -1, -1, 0};
+
+	// staging roles: thread -> (row = tid / 4, 4 consecutive k starting at (tid % 4) * 4)
+	const int srow = tid >> 2, sk = (tid & 3) * 4;
+	const int suid = (i0 + srow < a.users) ? (a.ulist ? a.ulist[i0 + srow] : i0 + srow) : -1;
+
+	for (int j0 = 0; j0 < a.items; j0 += kRT) {
+		double acc[4][4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u)
+#pragma unroll
+			for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+
+		for (int kc = 0; kc < K; kc += kRKC) {
+			{
+				const int ij = j0 + srow;
+#pragma unroll
+				for (int x = 0; x < 4; ++x) {
+					const int k = kc + sk + x;
+					Ls[sk + x][srow] = (suid >= 0 && k < K) ? a.L[(size_t) suid * K + k] : 0.0;
+					Rs[sk + x][srow] = (ij < a.items && k < K) ? a.R[(size_t) ij * K + k] : 0.0;
+				}
+			}
+			__syncthreads();
+			const int kmax = min(kRKC, K - kc);
+			for (int k = 0; k < kmax; ++k) {
+				double l[4], r[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) l[u] = Ls[k][ty * 4 + u];
+#pragma unroll
+				for (int v = 0; v < 4; ++v) r[v] = Rs[k][tx * 4 + v];
+#pragma unroll
+				for (int u = 0; u < 4; ++u)
+#pragma unroll
+					for (int v = 0; v < 4; ++v) acc[u][v] = acc[u][v] + l[u] * r[v];
+			}
+			__syncthreads();
+		}
+
+		// rated-item mask of this tile, one 64-bit word per user
+		if (tid < kRT) {
+			unsigned long long m = 0;
+			while (nextcol < j0 + kRT) {
+				if (nextcol >= j0) m |= 1ull << (nextcol - j0);
+				++cur;
+				nextcol = cur < cend ? a.csr_idx[cur] : INT32_MAX;
+			}
+			maskw[tid] = m;
+		}
+		__syncthreads();
+
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const unsigned long long m = maskw[ty * 4 + u];
+			Cand c{0.0, -1, -1, 0};
+#pragma unroll
+			for (int v = 0; v < 4; ++v) {
+				const int jj = tx * 4 + v;
+				if (j0 + jj < a.items && !((m >> jj) & 1ull)) cand_insert(c, acc[u][v], j0 + jj);
+			}
+			// ordered merge over the 16 lanes that hold this user's 64 items (ascending tx)
+#pragma unroll
+			for (int d = 1; d < 16; d <<= 1) {
+				Cand o;
+				o.bv = __shfl_down(c.bv, d, 16);
+				o.bi = __shfl_down(c.bi, d, 16);
+				o.first = __shfl_down(c.first, d, 16);
+				o.fnan = __shfl_down(c.fnan, d, 16);
+				if (tx + d < 16) cand_merge(c, o);
+			}
+			if (tx == 0) cand_merge(run[u], c);
+		}
+		__syncthreads();   // maskw is rewritten by the next tile
+	}
+
+	if (tx == 0) {
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const int i = i0 + ty * 4 + u;
+			if (i < a.users)
+				a.best[a.ulist ? a.ulist[i] : i] =
+				    run[u].first < 0 ? -1 : (run[u].fnan ? run[u].first : run[u].bi);
+		}
+	}
+}
+
+
+// Dense B = L R^T (mat2d_prod, mat2d.c:100-113) for the debug dump of small instances: one thread per
+// (i, j), sequential k from 0.0, separate multiply and add -- every element equals the reference's B[i][j].
+__global__ void __launch_bounds__(256) predict_kernel(const double *__restrict__ L, const double *__restrict__ R,
+                                                      int users, int items, int K, double *__restrict__ B)
+{
+	const size_t t = (size_t) blockIdx.x * 256 + threadIdx.x;
+	if (t >= (size_t) users * items) return;
+	const double *l = L + (t / items) * K, *r = R + (t % items) * K;
+	double b = 0.0;
+	for (int k = 0; k < K; ++k) b = b + l[k] * r[k];
+	B[t] = b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Recommend kernel, MFMA form: scores on the FP64 matrix cores, answers certified exact.
+//   pass 1 (this kernel)  S~ = L_blk * R^T with v_mfma_f64_16x16x4_f64; per user the best and the
+//          second-best score over unrated items are tracked.  For ANY summation order and fusing,
+//          |S~ - B| <= 2*gamma_K * |l|.|r| <= 2*gamma_K*||l||*||r||  (B = the reference's sequential,
+//          unfused value), so when best - second > thr_i = c*(K+8)*2^-53*||L[i]||*max_j||R[j]|| (c = 8, a
+//          4x margin) the approximate arg-max IS the reference's arg-max and no tie rule is involved.
+//   pass 2 (recommend_kernel with `ulist`)  every other user -- near-ties, exact ties (the lowest index
+//          must win), non-finite scores -- is re-scored in the reference's exact order.
+// Tile: 256 threads = 4 waves (2 x 2) own 128 users x 64 items per step; each wave holds 4 x 2
+// accumulator tiles of 16 x 16 (64 VGPRs); L and R k-chunks of 16 go through LDS stored k-major with a
+// leading dimension that puts the two 16-lane halves of a ds_read_b64 group on disjoint banks.
+// MFMA operand maps (f64 16x16x4): A lane l = A[l&15][l>>4], B lane l = B[l>>4][l&15],
+// D lane l reg r = D[(l>>4) + 4r][l&15].
+// ------------------------------------------------------------------------------------------------
+struct RecMfmaArgs {
+	int users, items, K;
+	const double *__restrict__ L;
+	const double *__restrict__ R;
+	const int *__restrict__ csr_ptr;
+	const int *__restrict__ csr_idx;
+	const double *__restrict__ lnorm;          // ||L[i]||_2 per user
+	const unsigned long long *__restrict__ rnorm_max_bits;   // max_j ||R[j]||_2 as the bits of a double
+	double thr_scale;                          // c * (K + 8) * 2^-53
+	int *__restrict__ best;
+	int *__restrict__ ulist;                   // out: users that need the exact pass
+	int *__restrict__ ucount;
+};
+
+__global__ void __launch_bounds__(kWave) row_norm_kernel(const double *__restrict__ X, int rows, int K,
+                                                          double *__restrict__ norm,
+                                                          unsigned long long *__restrict__ max_bits)
+{
+	const int r = blockIdx.x * kWave + threadIdx.x;
+	double s = 0.0;
+	if (r < rows)
+		for (int k = 0; k < K; ++k) {
+			const double v = X[(size_t) r * K + k];
+			s += v * v;
+		}
+	s = sqrt(s);
+	if (r < rows && norm) norm[r] = s;
+	if (max_bits) {
+		// NaN compares as a huge unsigned pattern: it poisons the maximum, which sends every user to pass 2
+		unsigned long long b = (r < rows) ? (unsigned long long) __double_as_longlong(s) : 0ull;
+		for (int d = 32; d >= 1; d >>= 1) {
+			const unsigned long long o = __shfl_xor(b, d);
+			b = o > b ? o : b;
+		}
+		if (threadIdx.x == 0) atomicMax(max_bits, b);
+	}
+}
+
+constexpr int kMU = 128, kMI = 128, kMKC = 32;
+// LDS image of a chunk: [k-pair][row] of double2 {x[row][2p], x[row][2p+1]}, 130 rows per k-pair.
+//   fragment read (ds_read_b64): lanes 0..31 = 16 rows x (k, k+1) of one pair -> 256 contiguous bytes;
+//   staging store (ds_write_b128): an 8-lane group = 2 rows x 4 k-pairs, pair stride 130*16 B = 8 banks mod 32.
+// Both are bank-conflict-free (the first version's [k][row] image conflicted 4-way on the stores).
+constexpr int kMLD2 = 130;
+constexpr int kMThreads = 512;
+
+struct Top2 {
+	double b1, b2;
+	int i1;
+};
+
+// b1 = -inf / i1 = -1 encode "no candidate"; all values are finite or -inf, so plain comparisons suffice
+__device__ __forceinline__ void top2_merge(Top2 &a, const Top2 &b)
+{
+	const bool take = b.b1 > a.b1;
+	const double lo1 = take ? a.b1 : b.b1;          // the smaller of the two bests
+	const double hi2 = take ? b.b2 : a.b2;          // the winner's own runner-up
+	a.b2 = lo1 > hi2 ? lo1 : hi2;
+	a.b1 = take ? b.b1 : a.b1;
+	a.i1 = take ? b.i1 : a.i1;
+}
+
+typedef double mf_d4 __attribute__((ext_vector_type(4)));
+
+// 512 threads = 8 waves as 4 (user quarters of 32) x 2 (item halves of 64): two waves per SIMD, so one
+// wave's staging, LDS traffic and arg-max bookkeeping run under the other's matrix instructions.
+template <bool VEC>   // VEC: K even -> rows are 16-B aligned, 16-byte global loads
+__global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a)
+{
+	__shared__ double2 As[2][kMKC / 2][kMLD2];   // double-buffered: one barrier per chunk
+	__shared__ double2 Bs[2][kMKC / 2][kMLD2];
+	__shared__ unsigned long long maskw[kMU][2];
+	__shared__ double red_b1[kMU][2], red_b2[kMU][2];
+	__shared__ int red_i1[kMU][2], red_bad[kMU][2];
+
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int wr = wave >> 1, wc = wave & 1;
+	const int lr = lane & 15, lq = lane >> 4;
+	const int i0 = blockIdx.x * kMU;
+	const int K = a.K;
+	const double ninf = -__builtin_inf();
+
+	// mask walker: threads 0..127, one user each
+	int cur = 0, cend = 0, nextcol = INT32_MAX;
+	if (tid < kMU && i0 + tid < a.users) {
+		cur = a.csr_ptr[i0 + tid];
+		cend = a.csr_ptr[i0 + tid + 1];
+		nextcol = cur < cend ? a.csr_idx[cur] : INT32_MAX;
+	}
+
+	// running top-2 of the 8 rows this lane sees: row(tu, r) = 32*wr + 16*tu + lq + 4*r
+	double b1[8], b2[8];
+	int i1[8];
+	unsigned bad = 0;
+#pragma unroll
+	for (int x = 0; x < 8; ++x) {
+		b1[x] = ninf;
+		b2[x] = ninf;
+		i1[x] = -1;
+	}
+
+	// staging roles: A and B chunks are 128 rows x 32 k; thread -> row tid/4, k-pairs 4m + (tid%4), m = 0..3
+	constexpr int SP = kMKC / 8;
+	const int srow = tid >> 2, sq = tid & 3;
+	const bool a_ok = i0 + srow < a.users;
+	const double *__restrict__ aptr = a.L + (size_t) (a_ok ? i0 + srow : 0) * K;
+	double2 av[SP], bv[SP];
+
+	// global -> registers for chunk (tile jt, k offset kc); zero outside the matrices
+	auto fetch = [&](int jt, int kc) {
+		const bool b_ok = jt + srow < a.items;
+		const double *__restrict__ bptr = a.R + (size_t) (b_ok ? jt + srow : 0) * K;
+#pragma unroll
+		for (int m = 0; m < SP; ++m) {
+			const int k = kc + 8 * m + 2 * sq;
+			if (VEC) {
+				av[m] = (a_ok && k < K) ? *reinterpret_cast<const double2 *>(aptr + k) : make_double2(0.0, 0.0);
+				bv[m] = (b_ok && k < K) ? *reinterpret_cast<const double2 *>(bptr + k) : make_double2(0.0, 0.0);
+			} else {
+				av[m].x = (a_ok && k < K) ? aptr[k] : 0.0;
+				av[m].y = (a_ok && k + 1 < K) ? aptr[k + 1] : 0.0;
+				bv[m].x = (b_ok && k < K) ? bptr[k] : 0.0;
+				bv[m].y = (b_ok && k + 1 < K) ? bptr[k + 1] : 0.0;
+			}
+		}
+	};
+	auto stage = [&](int buf) {
+#pragma unroll
+		for (int m = 0; m < SP; ++m) {
+			As[buf][4 * m + sq][srow] = av[m];
+			Bs[buf][4 * m + sq][srow] = bv[m];
+		}
+	};
+
+	int buf = 0;
+	fetch(0, 0);
+	stage(0);
+	__syncthreads();
+	for (int j0 = 0; j0 < a.items; j0 += kMI) {
+		mf_d4 acc[2][4];
+#pragma unroll
+		for (int tu = 0; tu < 2; ++tu)
+#pragma unroll
+			for (int ti = 0; ti < 4; ++ti) acc[tu][ti] = mf_d4{0.0, 0.0, 0.0, 0.0};
+
+		for (int kc = 0; kc < K; kc += kMKC) {
+			// next chunk (of this tile, or the first of the next tile): global loads fly behind the MFMAs
+			const bool more = kc + kMKC < K || j0 + kMI < a.items;
+			if (kc + kMKC < K)
+				fetch(j0, kc + kMKC);
+			else if (j0 + kMI < a.items)
+				fetch(j0 + kMI, 0);
+			const double *Ab = reinterpret_cast<const double *>(&As[buf][0][0]);
+			const double *Bb = reinterpret_cast<const double *>(&Bs[buf][0][0]);
+			auto kstep = [&](int ks) {
+				// k = 4*ks + lq -> pair 2*ks + (lq >> 1), half lq & 1
+				const int po = ((2 * ks + (lq >> 1)) * kMLD2) * 2 + (lq & 1);
+				double fa[2], fb[4];
+#pragma unroll
+				for (int tu = 0; tu < 2; ++tu) fa[tu] = Ab[po + (32 * wr + 16 * tu + lr) * 2];
+#pragma unroll
+				for (int ti = 0; ti < 4; ++ti) fb[ti] = Bb[po + (64 * wc + 16 * ti + lr) * 2];
+#pragma unroll
+				for (int tu = 0; tu < 2; ++tu)
+#pragma unroll
+					for (int ti = 0; ti < 4; ++ti)
+						acc[tu][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[tu], fb[ti], acc[tu][ti], 0, 0, 0);
+			};
+			if (kc + kMKC <= K) {
+#pragma unroll
+				for (int ks = 0; ks < kMKC / 4; ++ks) kstep(ks);
+			} else {   // last chunk: skip the zero padding beyond K
+				const int ksteps = (K - kc + 3) >> 2;
+				for (int ks = 0; ks < ksteps; ++ks) kstep(ks);
+			}
+			// registers -> the OTHER buffer (last read one chunk ago; every wave passed a barrier since)
+			if (more) stage(buf ^ 1);
+			__syncthreads();
+			buf ^= 1;
+		}
+
+		// rated-item mask of this tile: bit jj of word w = item j0 + 64*w + jj is rated or beyond the last item
+		if (tid < kMU) {
+			unsigned long long m0 = 0, m1 = 0;
+			while (nextcol < j0 + kMI) {
+				const int o = nextcol - j0;
+				if (o >= 64)
+					m1 |= 1ull << (o - 64);
+				else if (o >= 0)
+					m0 |= 1ull << o;
+				++cur;
+				nextcol = cur < cend ? a.csr_idx[cur] : INT32_MAX;
+			}
+			const int left = a.items - j0;   // > 0
+			if (left < 64) {
+				m0 |= ~0ull << left;
+				m1 = ~0ull;
+			} else if (left < 128) {
+				m1 |= ~0ull << (left - 64);
+			}
+			maskw[tid][0] = m0;
+			maskw[tid][1] = m1;
+		}
+		__syncthreads();
+#pragma unroll
+		for (int tu = 0; tu < 2; ++tu)
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const int x = tu * 4 + r;
+				const unsigned long long m = maskw[32 * wr + 16 * tu + lq + 4 * r][wc] >> lr;
+				// cheap reject: after the first tiles almost no score beats the row's runner-up
+				bool any = false;
+#pragma unroll
+				for (int ti = 0; ti < 4; ++ti) {
+					const double v = acc[tu][ti][r];
+					any |= !((m >> (16 * ti)) & 1ull) && !(v <= b2[x] && v >= -1.7976931348623157e308);   // v > b2, NaN, +-inf
+				}
+				if (__builtin_amdgcn_ballot_w64(any) != 0) {
+#pragma unroll
+					for (int ti = 0; ti < 4; ++ti) {
+						// branch-free insert: b1 starts at -inf, so "first candidate" needs no special case
+						const double v = acc[tu][ti][r];
+						const int j = j0 + 64 * wc + 16 * ti + lr;
+						const bool open = !((m >> (16 * ti)) & 1ull);
+						const bool fin = fabs(v) <= 1.7976931348623157e308;
+						bad |= (unsigned) (open && !fin) << x;
+						const bool use = open && fin;
+						const bool gt1 = use && v > b1[x];
+						const bool gt2 = use && !gt1 && v > b2[x];
+						b2[x] = gt1 ? b1[x] : (gt2 ? v : b2[x]);
+						b1[x] = gt1 ? v : b1[x];
+						i1[x] = gt1 ? j : i1[x];
+					}
+				}
+			}
+		__syncthreads();   // maskw is rewritten by the next tile
+	}
+
+	// merge the 16 lanes (lr) that share a row, then the two item halves (wc), then decide
+#pragma unroll
+	for (int x = 0; x < 8; ++x) {
+		Top2 t{b1[x], b2[x], i1[x]};
+		int bd = (bad >> x) & 1;
+#pragma unroll
+		for (int d = 1; d < 16; d <<= 1) {
+			Top2 o;
+			o.b1 = __shfl_xor(t.b1, d, 16);
+			o.b2 = __shfl_xor(t.b2, d, 16);
+			o.i1 = __shfl_xor(t.i1, d, 16);
+			bd |= __shfl_xor(bd, d, 16);
+			top2_merge(t, o);
+		}
+		if (lr == 0) {
+			const int row = 32 * wr + 16 * (x >> 2) + lq + 4 * (x & 3);
+			red_b1[row][wc] = t.b1;
+			red_b2[row][wc] = t.b2;
+			red_i1[row][wc] = t.i1;
+			red_bad[row][wc] = bd;
+		}
+	}
+	__syncthreads();
+	if (tid < kMU && i0 + tid < a.users) {
+		Top2 t{red_b1[tid][0], red_b2[tid][0], red_i1[tid][0]};
+		const Top2 o{red_b1[tid][1], red_b2[tid][1], red_i1[tid][1]};
+		top2_merge(t, o);
+		const int bd = red_bad[tid][0] | red_bad[tid][1];
+		const double rmax = __longlong_as_double((long long) *a.rnorm_max_bits);
+		const double thr = a.thr_scale * a.lnorm[i0 + tid] * rmax + 1e-300;
+		const bool certain = !bd && (t.i1 < 0 || (t.b1 - t.b2) > thr);
+		if (certain) {
+			a.best[i0 + tid] = t.i1;
+		} else {
+			a.best[i0 + tid] = -2;
+			a.ulist[atomicAdd(a.ucount, 1)] = i0 + tid;
+		}
+	}
+}
+
+}  // namespace mf

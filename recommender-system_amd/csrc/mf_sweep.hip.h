@@ -1,0 +1,580 @@
+// mf_sweep.hip.h -- gfx950 (CDNA4, wave64) kernels of the matrix-factorisation hot path.
+//
+// Both kernels are "owner computes": one wavefront owns one row of the factor it updates, so no atomics
+// are needed and every floating-point sum is formed in exactly the order the serial reference forms it
+// (matFact.c:41-53): the factor matrices come out BIT-IDENTICAL to matFact.c, not merely close.
+// Build with -ffp-contract=off: the reference multiplies and adds separately (no FMA).
+// This file: the sweep kernels (single-wave LDS-DMA form, products form, ordered sum, register-staged form)
+// and the row-cooperative form.
+#pragma once
+#include "mf_common.hip.h"
+
+namespace mf {
+
+// ------------------------------------------------------------------------------------------------
+// Sweep kernel.  One launch updates ONE factor from the frozen generation of both:
+//   user sweep:  X = L (rows = users of the shard),  Y = R,  (ptr, idx, val) = CSR of the shard
+//   item sweep:  X = R (rows = items),               Y = L,  (ptr, idx, val) = CSC of the shard
+// For the owned row r and each of its entries n (file order == ascending idx for sorted inputs):
+//   dot_n = sum_k X_old[r][k] * Y_old[idx_n][k]      sequential k, from 0.0       (mat2d.c:126-139)
+//   e_n   = (alpha*2) * (val_n - dot_n)                                            (matFact.c:45)
+//   X_new[r][k] = (...((seed + e_0*Y[idx_0][k]) + e_1*Y[idx_1][k]) + ...)          (matFact.c:47-51)
+// where seed = X_old[r][k], or 0 for the non-root contribution of a sharded item sweep
+// (matFact-mpi.c:187).  Mapping onto the wave, per chunk of <= nch entries of the row:
+//   stage   the nch gathered Y rows are copied, coalesced (16 B per lane), into an LDS tile whose row
+//           stride is odd in doubles, so both access patterns below are bank-conflict-free;
+//   phase A lane n walks row n of the tile and forms dot_n sequentially in k (the serial order) with
+//           X_old[r][k] as a scalar (SGPR) operand -> e_n;
+//   phase B lane l owns k = l, l+64, ...; loops n ascending, acc[k] += e_n * tile[n][k] with e_n
+//           broadcast by v_readlane -> the serial accumulation order into X[r][k].
+// Algorithmic HBM bytes per entry and sweep: 8K (the gathered row) + 12 (idx, val).
+// ------------------------------------------------------------------------------------------------
+struct SweepArgs {
+	int nrows;
+	int K;
+	int nch;      // entries per chunk (<= 64)
+	int stride;   // LDS row stride in doubles (odd)
+	int seed;     // 1: accumulate onto X_old, 0: onto zero
+	double c2;    // alpha * 2
+	const int *__restrict__ ptr;
+	const int *__restrict__ idx;
+	const double *__restrict__ val;
+	const double *__restrict__ X_old;
+	const double *__restrict__ Y_old;
+	double *__restrict__ X_new;
+	const int *__restrict__ rowlist;   // optional: the launch covers rows rowlist[0..nrows) instead of 0..nrows
+	// products mode (extreme rows): the launch covers SEGMENTS of rows; segment s = entries [seg_beg, seg_end) of row
+	// seg_row, whose scaled rows e_n * Y[idx_n][:] go to the scratch buffer at entry offset seg_out + (n - seg_beg)
+	const int *__restrict__ seg_row;
+	const int *__restrict__ seg_beg;
+	const int *__restrict__ seg_end;
+	const long long *__restrict__ seg_out;
+	double *__restrict__ scratch;
+	size_t scratch_entries;            // entries per 16-column slice of the scratch buffer
+};
+
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+	const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+	return __hiloint2double(hi, lo);
+}
+
+template <int KT, int KPMAX>
+__global__ void __launch_bounds__(kWave) sweep_kernel(SweepArgs a)
+{
+	extern __shared__ double tile[];
+	const int K = KT > 0 ? KT : a.K;
+	const int stride = KT > 0 ? (KT | 1) : a.stride;
+	const int nch = a.nch;
+	const int lane = threadIdx.x;
+
+	for (int it = blockIdx.x; it < a.nrows; it += gridDim.x) {
+		const int r = a.rowlist ? a.rowlist[it] : it;
+		const int beg = a.ptr[r], end = a.ptr[r + 1];
+		const double *__restrict__ xrow = a.X_old + (size_t) r * K;
+
+		double acc[KPMAX];
+#pragma unroll
+		for (int kk = 0; kk < KPMAX; ++kk) {
+			const int k = lane + kWave * kk;
+			acc[kk] = (a.seed && k < K) ? xrow[k] : 0.0;
+		}
+
+		for (int c = beg; c < end; c += nch) {
+			const int cnt = min(nch, end - c);
+			int my_idx = 0;
+			double my_val = 0.0;
+			if (lane < cnt) {
+				my_idx = a.idx[c + lane];
+				my_val = a.val[c + lane];
+			}
+			// ---- stage: gathered rows -> LDS tile (row n of the tile = Y_old[idx_n][:])
+			for (int n = 0; n < cnt; ++n) {
+				const int j = __builtin_amdgcn_readlane(my_idx, n);
+				const double *__restrict__ yrow = a.Y_old + (size_t) j * K;
+				double *trow = tile + n * stride;
+				if ((K & 1) == 0) {
+#pragma unroll 2
+					for (int q = lane; q < (K >> 1); q += kWave) {
+						const double2 v = *reinterpret_cast<const double2 *>(yrow + 2 * q);
+						trow[2 * q] = v.x;
+						trow[2 * q + 1] = v.y;
+					}
+				} else {
+					for (int q = lane; q < K; q += kWave)
+						trow[q] = yrow[q];
+				}
+			}
+			__syncthreads();
+			// ---- phase A: lane n -> e_n (all lanes run it; lanes >= cnt produce unused garbage)
+			double e;
+			{
+				const double *t = tile + (lane < nch ? lane : 0) * stride;   // lanes beyond the tile re-read row 0
+				double dot = 0.0;
+#pragma unroll 8
+				for (int k = 0; k < K; ++k)
+					dot = dot + xrow[k] * t[k];
+				e = a.c2 * (my_val - dot);
+			}
+			// ---- phase B: lane l -> columns l, l+64, ...; entries in order
+			for (int n = 0; n < cnt; ++n) {
+				const double en = readlane_f64(e, n);
+				const double *t = tile + n * stride;
+#pragma unroll
+				for (int kk = 0; kk < KPMAX; ++kk) {
+					const int k = lane + kWave * kk;
+					if (k < K)
+						acc[kk] = acc[kk] + en * t[k];
+				}
+			}
+			__syncthreads();
+		}
+#pragma unroll
+		for (int kk = 0; kk < KPMAX; ++kk) {
+			const int k = lane + kWave * kk;
+			if (k < K)
+				a.X_new[(size_t) r * K + k] = acc[kk];
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sweep kernel, LDS-DMA form (the production kernel for even, compile-time K).
+// Same arithmetic, same order, as sweep_kernel above; what changes is how the bytes move:
+//   stage   one `global_load_lds_dwordx4` per gathered row (K/2 lanes x 16 B, per-lane source address,
+//           wave-uniform LDS row base): the whole chunk -- up to 64 rows, 51 KB at K=100 -- is in flight
+//           at once with no VGPR staging and no ds_write; one vmcnt(0) retires it.
+//   tile    row stride = 16 B x (odd), so phase A's ds_read_b128 (lane n -> row n, 16-lane groups) is
+//           bank-conflict-free while every row stays 16-B aligned for the DMA.
+//   phase A lane n: 16 B of its row + 16 B of x (LDS broadcast) per step, two sequential mul/add pairs.
+//   phase B lane l owns columns 2l, 2l+1 (+128 per pass): one ds_read_b128 per entry and pass, entries
+//           in order, e_n broadcast through v_readlane into a scalar operand.
+// LDS: [ x row: XS bytes ][ tile: nch rows x S bytes ].
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void mf_gvoid;
+typedef __attribute__((address_space(3))) void mf_lvoid;
+
+template <int KT>
+struct DmaGeom {
+	static_assert(KT % 2 == 0 && KT >= 2, "LDS-DMA sweep needs an even K");
+	static constexpr int kPieces = KT / 2;                        // 16-B pieces per row
+	static constexpr int kPasses = (kPieces + kWave - 1) / kWave; // DMA instructions per row
+	static constexpr int kStride = 16 * (kPieces | 1);            // bytes, odd multiple of 16
+	static constexpr int kXsBytes = ((KT * 8 + 255) / 256) * 256;
+};
+
+// KT > 0: K is a compile-time constant (phase A fully unrolled).  KT == 0: any even K up to 128*NPASS at run
+// time (phase A unrolled by four) -- same data movement, so an unusual K does not fall back to the
+// register-staged kernel.
+// PRODUCTS = true: the "extreme row" form -- one wave per SEGMENT of a very long row; instead of accumulating, the
+// scaled rows p_n[k] = e_n * y_n[k] (the rounded product the serial loop adds) are stored to a scratch buffer in
+// entry order, and ordered_sum_kernel adds them up in that order afterwards.  Thousands of segments run in
+// parallel, so a row rated by every user costs a chip-wide pass plus one serial chain of adds.
+template <int KT, int NPASS, bool PRODUCTS = false>
+__global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
+{
+	const int K = KT > 0 ? KT : a.K;
+	const int P = K >> 1;                                   // 16-B pieces per row
+	constexpr int NP = NPASS;                               // DMA instructions per row
+	const int S = 16 * (P | 1);                             // tile row stride, odd multiple of 16 B
+	const int xs_bytes = ((K * 8 + 255) / 256) * 256;
+	extern __shared__ __attribute__((aligned(16))) char lds[];
+	double2 *xs = reinterpret_cast<double2 *>(lds);
+	char *tile = lds + xs_bytes;
+	const int nch = a.nch;
+	const int lane = threadIdx.x;
+	const unsigned voff = (unsigned) lane * 16u;
+	const unsigned long long ybase = (unsigned long long) a.Y_old;
+
+	for (int it = blockIdx.x; it < a.nrows; it += gridDim.x) {
+		const int r = PRODUCTS ? a.seg_row[it] : (a.rowlist ? a.rowlist[it] : it);
+		const int beg = PRODUCTS ? a.seg_beg[it] : a.ptr[r];
+		const int end = PRODUCTS ? a.seg_end[it] : a.ptr[r + 1];
+		const double2 *__restrict__ xrow2 = reinterpret_cast<const double2 *>(a.X_old + (size_t) r * K);
+
+		double2 acc[NP];
+#pragma unroll
+		for (int p = 0; p < NP; ++p) {
+			const int q = lane + kWave * p;
+			double2 v = make_double2(0.0, 0.0);
+			if (q < P) {
+				v = xrow2[q];
+				xs[q] = v;
+			}
+			acc[p] = a.seed ? v : make_double2(0.0, 0.0);
+		}
+
+		// (idx, val) of a chunk are loaded one chunk ahead, so the gather of chunk c never waits on them
+		int nx_idx = 0;
+		double nx_val = 0.0;
+		if (beg + lane < min(end, beg + nch)) {
+			nx_idx = a.idx[beg + lane];
+			nx_val = a.val[beg + lane];
+		}
+		for (int c = beg; c < end; c += nch) {
+			const int cnt = min(nch, end - c);
+			const int my_idx = nx_idx;
+			const double my_val = nx_val;
+			if (c + nch + lane < min(end, c + 2 * nch)) {
+				nx_idx = a.idx[c + nch + lane];
+				nx_val = a.val[c + nch + lane];
+			}
+			// ---- stage: one DMA per gathered row and pass
+			for (int n = 0; n < cnt; ++n) {
+				const int j = __builtin_amdgcn_readlane(my_idx, n);
+				unsigned long long base = ybase + (unsigned long long) (unsigned) j * (unsigned long long) (K * 8);
+				asm volatile("" : "+s"(base));   // keep the row base scalar
+#pragma unroll
+				for (int p = 0; p < NP; ++p) {
+					const char *src = reinterpret_cast<const char *>(base) + voff + 1024u * p;
+					if (lane + kWave * p < P)
+						__builtin_amdgcn_global_load_lds((mf_gvoid *) src, (mf_lvoid *) (tile + n * S + 1024 * p),
+						                                 16, 0, 0);
+				}
+			}
+			__syncthreads();   // single-wave workgroup: this is the vmcnt(0)/lgkmcnt(0) that retires the DMA
+			// ---- phase A
+			double e;
+			{
+				const double2 *t2 = reinterpret_cast<const double2 *>(tile + (lane < nch ? lane : 0) * S);   // lanes beyond the tile re-read row 0
+				double dot = 0.0;
+				if (KT > 0) {
+#pragma unroll
+					for (int q = 0; q < KT / 2; ++q) {
+						const double2 t = t2[q];
+						const double2 x = xs[q];
+						dot = dot + x.x * t.x;
+						dot = dot + x.y * t.y;
+					}
+				} else {
+					int q = 0;
+					for (; q + 4 <= P; q += 4) {
+						double2 t[4], x[4];
+#pragma unroll
+						for (int u = 0; u < 4; ++u) {
+							t[u] = t2[q + u];
+							x[u] = xs[q + u];
+						}
+#pragma unroll
+						for (int u = 0; u < 4; ++u) {
+							dot = dot + x[u].x * t[u].x;
+							dot = dot + x[u].y * t[u].y;
+						}
+					}
+					for (; q < P; ++q) {
+						const double2 t = t2[q];
+						const double2 x = xs[q];
+						dot = dot + x.x * t.x;
+						dot = dot + x.y * t.y;
+					}
+				}
+				e = a.c2 * (my_val - dot);
+			}
+			if (PRODUCTS) {
+				// scratch layout: [k-slice of 16 columns][entry][16 doubles] -- every (slice, entry) is one aligned
+				// 128-B line and a slice is contiguous over the entries, so ordered_sum_kernel streams it linearly
+				const char *tb = tile + voff;
+				const size_t pos = (size_t) (a.seg_out[it] + (c - beg));
+				for (int n = 0; n < cnt; ++n) {
+					const double en = readlane_f64(e, n);
+#pragma unroll
+					for (int p = 0; p < NP; ++p) {
+						const int q = lane + kWave * p;   // 16-B piece: slice q / 8, position q % 8 in its line
+						if (q < P) {
+							double2 t = *reinterpret_cast<const double2 *>(tb + n * S + 1024 * p);
+							t.x = en * t.x;
+							t.y = en * t.y;
+							*reinterpret_cast<double2 *>(a.scratch + (((size_t) (q >> 3) * a.scratch_entries + pos + n) << 4) +
+							                             2 * (q & 7)) = t;
+						}
+					}
+				}
+				__syncthreads();
+				continue;
+			}
+			// ---- phase B
+			const char *tb = tile + voff;
+			int n = 0;
+			for (; n + 4 <= cnt; n += 4) {
+				double2 t[4][NP];
+				double en[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					en[u] = readlane_f64(e, n + u);
+#pragma unroll
+					for (int p = 0; p < NP; ++p)
+						t[u][p] = (lane + kWave * p < P)
+						              ? *reinterpret_cast<const double2 *>(tb + (n + u) * S + 1024 * p)
+						              : make_double2(0.0, 0.0);
+				}
+#pragma unroll
+				for (int u = 0; u < 4; ++u)
+#pragma unroll
+					for (int p = 0; p < NP; ++p) {
+						acc[p].x = acc[p].x + en[u] * t[u][p].x;
+						acc[p].y = acc[p].y + en[u] * t[u][p].y;
+					}
+			}
+			for (; n < cnt; ++n) {
+				const double en = readlane_f64(e, n);
+#pragma unroll
+				for (int p = 0; p < NP; ++p)
+					if (lane + kWave * p < P) {
+						const double2 t = *reinterpret_cast<const double2 *>(tb + n * S + 1024 * p);
+						acc[p].x = acc[p].x + en * t.x;
+						acc[p].y = acc[p].y + en * t.y;
+					}
+			}
+			__syncthreads();   // tile is overwritten by the next chunk's DMA
+		}
+		if (!PRODUCTS) {
+			double2 *__restrict__ out2 = reinterpret_cast<double2 *>(a.X_new + (size_t) r * K);
+#pragma unroll
+			for (int p = 0; p < NP; ++p) {
+				const int q = lane + kWave * p;
+				if (q < P) out2[q] = acc[p];
+			}
+		}
+	}
+}
+
+// Ordered sum of the scaled rows of one extreme row: X_new[r][k] = (...((seed + p_0[k]) + p_1[k]) + ...), the
+// serial accumulation order.  One wave per (row, 16-column slice).  The slice is contiguous over the entries
+// (128 B each), so ONE LDS-DMA instruction brings a block of 8 consecutive entries (1 KiB, lane-linear) into a
+// slot of a 32-slot LDS ring, and the wave keeps 31 blocks -- 248 entries -- in flight ahead of the block it is
+// adding: that hides the ~2 us read latency behind the only true critical path, the chain of dependent adds.
+// The DMA and its s_waitcnt are inline asm with hand-counted vmcnt (hipcc would otherwise wait vmcnt(0) before
+// every LDS read that may alias a pending LDS-DMA); no prefetch registers exist, so nothing can be sunk or
+// spilled.  Every lane (piece = lane & 7) walks the 8 entries of a block in order; the eight lane groups hold
+// identical sums.
+struct OrderedSumArgs {
+	int nrows, K, seed, nslices;
+	const int *__restrict__ row;          // extreme row ids
+	const long long *__restrict__ sbeg;   // first scratch entry of the row
+	const int *__restrict__ cnt;          // entries of the row
+	const double *__restrict__ scratch;   // [slice][entry][16], each slice padded by 8 entries
+	size_t scratch_entries;
+	const double *__restrict__ X_old;
+	double *__restrict__ X_new;
+};
+
+constexpr int kRing = 32;   // LDS ring slots of 1 KiB
+
+__global__ void __launch_bounds__(kWave) ordered_sum_kernel(OrderedSumArgs a)
+{
+	__shared__ __attribute__((aligned(1024))) char ring[kRing * 1024];
+	const int lane = threadIdx.x, K = a.K;
+	const unsigned ring_base = (unsigned) (unsigned long long) (__attribute__((address_space(3))) char *) ring;
+	const char *my = ring + 16 * (lane & 7);          // this lane's piece inside an entry
+	const int total = a.nrows * a.nslices;
+	for (int it = blockIdx.x; it < total; it += gridDim.x) {
+		const int li = it / a.nslices, slice = it % a.nslices;
+		const int r = a.row[li], cnt = a.cnt[li];
+		const int k0 = slice * 16 + 2 * (lane & 7);       // this lane's two columns (all 8 lane groups agree)
+		const bool live = k0 < K;                         // K is even: k0 + 1 < K too
+		double2 acc = (a.seed && live) ? *reinterpret_cast<const double2 *>(a.X_old + (size_t) r * K + k0)
+		                               : make_double2(0.0, 0.0);
+		// block b of the row in this slice: 8 entries = 1 KiB at ((slice * entries + sbeg + 8b) * 128) bytes
+		const char *src = reinterpret_cast<const char *>(
+		                      a.scratch + (((size_t) slice * a.scratch_entries + (size_t) a.sbeg[li]) << 4)) +
+		                  16 * lane;
+		const int nblk = (cnt + 7) >> 3;
+
+		// every ordinary load above must have landed before the hand-counted region starts
+		asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+		auto issue = [&](int b) {
+			const char *g = src + (size_t) b * 1024;
+			const unsigned m0 = ring_base + (unsigned) (b & (kRing - 1)) * 1024u;
+			asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0) : "memory");   // m0 is a reserved register: hipcc re-loads it before each of its own uses
+		};
+		auto add_block = [&](int b, int entries) {
+			const char *slot = my + (b & (kRing - 1)) * 1024;
+			if (entries == 8) {
+				double2 v[8];
+#pragma unroll
+				for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const double2 *>(slot + 128 * e);
+#pragma unroll
+				for (int e = 0; e < 8; ++e) {
+					acc.x = acc.x + v[e].x;
+					acc.y = acc.y + v[e].y;
+				}
+			} else {
+				for (int e = 0; e < entries; ++e) {
+					const double2 v = *reinterpret_cast<const double2 *>(slot + 128 * e);
+					acc.x = acc.x + v.x;
+					acc.y = acc.y + v.y;
+				}
+			}
+		};
+		const int ahead = min(nblk, kRing - 1);
+		for (int b = 0; b < ahead; ++b) issue(b);
+		int b = 0;
+		// steady state: kRing-1 blocks are issued beyond b-1, so block b has landed once at most kRing-2 newer DMAs
+		// are outstanding; after adding it, its predecessor's slot is refilled (its LDS reads were consumed by the adds)
+		for (; b + (kRing - 1) < nblk; ++b) {
+			asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+			add_block(b, 8);
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			issue(b + kRing - 1);
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		for (; b < nblk; ++b) add_block(b, min(8, cnt - 8 * b));
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the ring is reused by the next (row, slice)
+		if (live && lane < 8) *reinterpret_cast<double2 *>(a.X_new + (size_t) r * K + k0) = acc;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sweep kernel, row-cooperative form: for launches with FEW rows (ML100k: 943 users / 1682 items), where
+// one wave walking a long row alone (737 entries = 47 chunks) is the whole launch time.  A workgroup of
+// 8 waves owns one row.  Waves 1..7 ("producers") each take one chunk per round: LDS-DMA gather, phase A
+// (sequential-k dots -> e_n) and then SCALE their tile in place, p_n[k] = e_n * y_n[k] (the same rounded
+// product the serial loop forms).  Wave 0 (the "accumulator") only walks the finished tiles in entry order
+// doing acc[k] = acc[k] + p_n[k]: the serial chain per entry is one dependent add instead of a whole chunk
+// pipeline, while the producers already fill the other tile buffer for the next round (double-buffered,
+// one barrier per round).  Same arithmetic, same order: results stay bit-identical to the serial reference.
+// LDS: [ x row ][ 2 buffers x 7 producers x nch rows x S bytes ].
+// ------------------------------------------------------------------------------------------------
+constexpr int kCoopWaves = 8;
+constexpr int kCoopProducers = kCoopWaves - 1;
+
+template <int KT>
+__global__ void __launch_bounds__(kCoopWaves *kWave) sweep_coop_kernel(SweepArgs a)
+{
+	using G = DmaGeom<KT>;
+	constexpr int K = KT, P = G::kPieces, NP = G::kPasses, S = G::kStride;
+	extern __shared__ __attribute__((aligned(16))) char lds[];
+	double2 *xs = reinterpret_cast<double2 *>(lds);
+	const int nch = a.nch;
+	const int tile_bytes = nch * S;
+	char *tiles = lds + G::kXsBytes;   // tile(buf, p) = tiles + (buf * kCoopProducers + p) * tile_bytes
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const unsigned voff = (unsigned) lane * 16u;
+	const unsigned long long ybase = (unsigned long long) a.Y_old;
+	const int per_round = kCoopProducers * nch;
+
+	for (int it = blockIdx.x; it < a.nrows; it += gridDim.x) {
+		const int r = a.rowlist ? a.rowlist[it] : it;
+		const int beg = a.ptr[r], end = a.ptr[r + 1];
+		const double2 *__restrict__ xrow2 = reinterpret_cast<const double2 *>(a.X_old + (size_t) r * K);
+		double2 acc[NP];
+#pragma unroll
+		for (int p = 0; p < NP; ++p) acc[p] = make_double2(0.0, 0.0);
+		if (wave == 0) {
+#pragma unroll
+			for (int p = 0; p < NP; ++p) {
+				const int q = lane + kWave * p;
+				if (q < P) {
+					const double2 v = xrow2[q];
+					xs[q] = v;
+					if (a.seed) acc[p] = v;
+				}
+			}
+		}
+		__syncthreads();
+		const int rounds = (end - beg + per_round - 1) / per_round;
+		for (int round = 0; round <= rounds; ++round) {
+			if (wave > 0) {
+				// ---- producer: chunk (round, wave-1) -> buffer round&1
+				const int c = beg + round * per_round + (wave - 1) * nch;
+				const int cnt = round < rounds ? max(0, min(nch, end - c)) : 0;
+				if (cnt > 0) {
+					char *tile = tiles + ((round & 1) * kCoopProducers + (wave - 1)) * tile_bytes;
+					int my_idx = 0;
+					double my_val = 0.0;
+					if (lane < cnt) {
+						my_idx = a.idx[c + lane];
+						my_val = a.val[c + lane];
+					}
+					for (int n = 0; n < cnt; ++n) {
+						const int j = __builtin_amdgcn_readlane(my_idx, n);
+						unsigned long long base = ybase + (unsigned long long) (unsigned) j * (unsigned long long) (K * 8);
+						asm volatile("" : "+s"(base));
+#pragma unroll
+						for (int p = 0; p < NP; ++p) {
+							const char *src = reinterpret_cast<const char *>(base) + voff + 1024u * p;
+							if (lane + kWave * p < P)
+								__builtin_amdgcn_global_load_lds((mf_gvoid *) src,
+								                                 (mf_lvoid *) (tile + n * S + 1024 * p), 16, 0, 0);
+						}
+					}
+					__builtin_amdgcn_s_waitcnt(0);          // vmcnt(0): the DMA has landed (single wave owns the tile)
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+					double e;
+					{
+						const double2 *t2 = reinterpret_cast<const double2 *>(tile + (lane < nch ? lane : 0) * S);   // lanes beyond the tile re-read row 0
+						double dot = 0.0;
+#pragma unroll
+						for (int q = 0; q < P; ++q) {
+							const double2 t = t2[q];
+							const double2 x = xs[q];
+							dot = dot + x.x * t.x;
+							dot = dot + x.y * t.y;
+						}
+						e = a.c2 * (my_val - dot);
+					}
+					// scale in place: p_n[k] = e_n * y_n[k]
+					char *tb = tile + voff;
+					for (int n = 0; n < cnt; ++n) {
+						const double en = readlane_f64(e, n);
+#pragma unroll
+						for (int p = 0; p < NP; ++p)
+							if (lane + kWave * p < P) {
+								double2 *slot = reinterpret_cast<double2 *>(tb + n * S + 1024 * p);
+								double2 t = *slot;
+								t.x = en * t.x;
+								t.y = en * t.y;
+								*slot = t;
+							}
+					}
+				}
+			} else if (round > 0) {
+				// ---- accumulator: the tiles of round-1, producers in order, entries in order
+				const int base_c = beg + (round - 1) * per_round;
+				for (int pw = 0; pw < kCoopProducers; ++pw) {
+					const int cnt = max(0, min(nch, end - (base_c + pw * nch)));
+					const char *tb = tiles + (((round - 1) & 1) * kCoopProducers + pw) * tile_bytes + voff;
+					int n = 0;
+					for (; n + 8 <= cnt; n += 8) {
+						double2 t[8][NP];
+#pragma unroll
+						for (int u = 0; u < 8; ++u)
+#pragma unroll
+							for (int p = 0; p < NP; ++p)
+								t[u][p] = (lane + kWave * p < P)
+								              ? *reinterpret_cast<const double2 *>(tb + (n + u) * S + 1024 * p)
+								              : make_double2(0.0, 0.0);
+#pragma unroll
+						for (int u = 0; u < 8; ++u)
+#pragma unroll
+							for (int p = 0; p < NP; ++p) {
+								acc[p].x = acc[p].x + t[u][p].x;
+								acc[p].y = acc[p].y + t[u][p].y;
+							}
+					}
+					for (; n < cnt; ++n)
+#pragma unroll
+						for (int p = 0; p < NP; ++p)
+							if (lane + kWave * p < P) {
+								const double2 t = *reinterpret_cast<const double2 *>(tb + n * S + 1024 * p);
+								acc[p].x = acc[p].x + t.x;
+								acc[p].y = acc[p].y + t.y;
+							}
+				}
+			}
+			__syncthreads();
+		}
+		if (wave == 0) {
+			double2 *__restrict__ out2 = reinterpret_cast<double2 *>(a.X_new + (size_t) r * K);
+#pragma unroll
+			for (int p = 0; p < NP; ++p) {
+				const int q = lane + kWave * p;
+				if (q < P) out2[q] = acc[p];
+			}
+		}
+		__syncthreads();   // xs is rewritten for the next row
+	}
+}
+
+}  // namespace mf

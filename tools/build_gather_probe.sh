@@ -1,5 +1,5 @@
 #!/bin/bash
-# Builds recommender-system_amd/csrc/libprobe_gather.so: the same library with phases A and B of the LDS-DMA sweep
+# Builds recommender-system_amd/csrc/libprobe_gather.so: the same library with phases A and B of the LDS-DMA sweep (mf_sweep.hip.h)
 # replaced by one token LDS read per chunk (results are wrong; only the timing matters).  Run the bench with
 #   MF_HIP_LIB=$PWD/recommender-system_amd/csrc/libprobe_gather.so python bench.py --no-cpu-baseline
 # to measure the ceiling of the gather itself.  Round 1: probe 23.9 ms/iter vs real kernel 23.95 ms/iter on cfg4 --
@@ -8,13 +8,14 @@ set -e
 cd "$(dirname "$0")/.."
 tmp=$(mktemp -d)
 cp -r recommender-system_amd include "$tmp/"
-python3 - "$tmp/recommender-system_amd/csrc/mf_kernels.hip.h" <<'PY'
+python3 - "$tmp/recommender-system_amd/csrc/mf_sweep.hip.h" <<'PY'
 import sys
 p = sys.argv[1]
 s = open(p).read()
-a = s.index("			// ---- phase A\n			double e;\n			{\n				const double2 *t2 = reinterpret_cast<const double2 *>(tile + lane * S);\n				double dot = 0.0;\n				if (KT > 0) {")
-b = s.index("			__syncthreads();   // tile is overwritten by the next chunk's DMA")
-s = s[:a] + "			{\n				const double2 *t2 = reinterpret_cast<const double2 *>(tile + lane * S);\n				acc[0].x = acc[0].x + t2[0].x * my_val;\n			}\n" + s[b:]
+k = s.index("__global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)")
+a = s.index("			// ---- phase A\n", k)
+b = s.index("			__syncthreads();   // tile is overwritten by the next chunk's DMA", a)
+s = s[:a] + "			{\n				const double2 *t2 = reinterpret_cast<const double2 *>(tile + (lane < nch ? lane : 0) * S);\n				acc[0].x = acc[0].x + t2[0].x * my_val;\n			}\n" + s[b:]
 open(p, "w").write(s)
 PY
 hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math -std=c++17 -fPIC -shared \
