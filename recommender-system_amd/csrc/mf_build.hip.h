@@ -348,11 +348,9 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 			MF_TRY_HIP(hipMemcpy(p->lr_cnt[kind], lcnt.data(), lg.size() * sizeof(int), hipMemcpyHostToDevice));
 		}
 		if (p->coop_all[0] || p->coop_all[1])
-			MF_TRY_HIP(hipFuncSetAttribute((const void *) p->sweep.coop, hipFuncAttributeMaxDynamicSharedMemorySize,
-			                               (int) p->lds_bytes_coop));
+			MF_TRY_HIP(raise_lds_limit((const void *) p->sweep.coop, p->lds_bytes_coop));
 		if (p->n_long[0] || p->n_long[1]) {
-			MF_TRY_HIP(hipFuncSetAttribute((const void *) p->sweep.prod, hipFuncAttributeMaxDynamicSharedMemorySize,
-			                               (int) p->lds_bytes));
+			MF_TRY_HIP(raise_lds_limit((const void *) p->sweep.prod, p->lds_bytes));
 			// [16-column slice][entry][16 doubles]; 8 entries of padding per slice: the last block of a row is read whole
 			p->scratch_entries = (size_t) scratch_entries + 8;
 			MF_TRY(dev_alloc(&p->scratch, p->scratch_entries * 16 * (size_t) ((p->K + 15) / 16)));

@@ -1,6 +1,8 @@
 // mf_hip.hip -- C ABI (include/matfact_hip.h) of the MI355X backend: plan management, CSR/CSC build,
 // kernel dispatch.  HIP only -- there is no CPU compute path in this library.
 #include <cstring>
+#include <map>
+#include <mutex>
 
 #include "../../include/matfact_hip.h"
 #include "mf_kernels.hip.h"

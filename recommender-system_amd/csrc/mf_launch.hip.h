@@ -58,8 +58,7 @@ int choose_sweep(mf_plan *p)
 	if (getenv("MF_SWEEP_NCH")) few = nch;
 	p->nch_few = few;
 	p->lds_bytes_few = head + (size_t) few * row_bytes;
-	MF_HIP(hipFuncSetAttribute((const void *) p->sweep.fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-	                           (int) std::max(p->lds_bytes, p->lds_bytes_few)));
+	MF_HIP(raise_lds_limit((const void *) p->sweep.fn, (size_t) (std::max(p->lds_bytes, p->lds_bytes_few))));
 	return MF_OK;
 }
 

@@ -16,6 +16,20 @@ thread_local std::string g_last_hip_error;
 
 using SweepFn = void (*)(mf::SweepArgs);
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is per FUNCTION, not per plan: two live plans that share a kernel
+// instance (the run-time-K forms) but need different tile sizes must never lower each other's limit.
+inline hipError_t raise_lds_limit(const void *fn, size_t bytes)
+{
+	static std::mutex mu;
+	static std::map<const void *, size_t> limit;
+	std::lock_guard<std::mutex> lock(mu);
+	size_t &cur = limit[fn];
+	if (bytes <= cur) return hipSuccess;
+	const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
+	if (e == hipSuccess) cur = bytes;
+	return e;
+}
+
 struct SweepVariant {
 	SweepFn fn;
 	int kt;         // compile-time K, 0 = runtime K

@@ -521,3 +521,24 @@ def test_degenerate_shapes(capi, orc, u, i, k):
         L2, R2 = capi.init_factors(u, i, k)
         best2 = capi.backend_run_multi(_inst(capi, d), L2, R2, [0, 0])
         assert np.allclose(L2, Lo, rtol=1e-9, atol=1e-13) and np.array_equal(best2, bo)
+
+
+def test_two_live_plans_sharing_a_run_time_k_kernel(capi, orc):
+    """Two plans alive at once whose K map to the SAME run-time-K kernel instance but different LDS tile sizes
+    (the dynamic-LDS limit is a per-function attribute and must only ever be raised)."""
+    da = random_instance(1, 60, 50, 96, density=0.3, iters=2)
+    db = random_instance(2, 40, 70, 64, density=0.3, iters=2)
+    pa = capi.Plan(60, 50, 96, da["alpha"], da["row"], da["col"], da["val"])
+    pb = capi.Plan(40, 70, 64, db["alpha"], db["row"], db["col"], db["val"])     # created second, smaller tiles
+    out = []
+    for plan, d, (u, i, k) in ((pa, da, (60, 50, 96)), (pb, db, (40, 70, 64))):
+        L, R = capi.init_factors(u, i, k)
+        plan.upload(L, R)
+    pa.iterate(2)
+    pb.iterate(2)
+    for plan, d, (u, i, k) in ((pa, da, (60, 50, 96)), (pb, db, (40, 70, 64))):
+        Lg, Rg = plan.download()
+        Lo, Ro = orc.init_factors(u, i, k)
+        orc.factorize(orc.Instance(**d), Lo, Ro, iters=2)
+        assert np.array_equal(Lg, Lo) and np.array_equal(Rg, Ro)
+        plan.close()
