@@ -60,6 +60,10 @@ int mf_plan_create(mf_plan **out, const mf_shard *s)
 	    s->user_count < 0 || (int64_t) s->user_begin + s->user_count > s->users_total ||
 	    s->nnz > INT32_MAX - 64 || (s->nnz > 0 && (!s->row || !s->col || !s->val)))
 		return MF_ERR_ARGUMENT;
+	// caller-owned R buffers: both or neither, and 16-B aligned (the gather moves 16-byte pieces of rows)
+	if ((s->items_ext[0] == nullptr) != (s->items_ext[1] == nullptr) || ((uintptr_t) s->items_ext[0] & 15) ||
+	    ((uintptr_t) s->items_ext[1] & 15) || (s->items_ext[0] && s->items_ext[0] == s->items_ext[1]))
+		return MF_ERR_ARGUMENT;
 	const int ndev = mf_backend_device_count();
 	if (ndev <= 0 || s->device < 0 || s->device >= ndev) return MF_ERR_NO_DEVICE;
 	MF_HIP(hipSetDevice(s->device));
