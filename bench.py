@@ -31,6 +31,9 @@ CONFIGS = {
     "cfg5": dict(users=1_000_000, items=1_000_000, feats=256, min_row=250, max_row=750, alpha=1e-5, seed=0xC0FFEE + 5),
     "cfg3": dict(users=6040, items=3952, feats=100, min_row=20, max_row=311, alpha=1e-4, seed=0xC0FFEE + 3),
     "twin": dict(users=10_000, items=1_000, feats=100, min_row=50, max_row=150, alpha=1e-4, seed=0xC0FFEE + 4),
+    # BASELINE.json configs[1]: the reference's own MovieLens-100k sample (real data, shipped as a test fixture)
+    "ml100k": dict(file=os.path.join(ROOT, "tests", "golden", "instML100k.in.gz"), users=943, items=1682, feats=30,
+                   min_row=20, max_row=737, alpha=1e-4, seed=0),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -179,6 +182,12 @@ def main():
     begin = capi.partition_users(U, world, ptr if args.partition == "entries" else None)
     u0, uc = int(begin[rank]), int(begin[rank + 1] - begin[rank])
     row, col, val = capi.synth_block(cfg["seed"], U, I, cfg["min_row"], cfg["max_row"], u0, uc)
+    if cfg.get("file"):
+        if world != 1:
+            raise SystemExit("--config %s: single rank only" % args.config)
+        inst = capi.parse_file(cfg["file"])
+        assert (inst.users, inst.items, inst.feats) == (U, I, K)
+        row, col, val, total_nnz = inst.row, inst.col, inst.val, inst.nnz
     if args.skew:
         if world != 1 or U * I > 5e8:
             raise SystemExit("--skew: single rank and users*items <= 5e8 only")
@@ -251,9 +260,11 @@ def main():
     out = {
         "metric": "nnz_updates_per_sec", "value": total_nnz * args.steps / elapsed, "unit": "nnz-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": ("%s: synthetic %dx%d, K=%d, nnz=%d, alpha=%g, " % (args.config, U, I, K, total_nnz, cfg["alpha"]))
-                               + ("power-law rows and item popularity" if args.skew else
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "real (reference sample)" if cfg.get("file") else "synthetic",
+        "config": {"workload": ("%s: %s%dx%d, K=%d, nnz=%d, alpha=%g, " % (args.config, "" if cfg.get("file") else "synthetic ",
+                                                                      U, I, K, total_nnz, cfg["alpha"]))
+                               + ("the reference's samples/instML100k.in (real data)" if cfg.get("file") else
+                                  "power-law rows and item popularity" if args.skew else
                                   "rows %d..%d entries, uniform columns" % (cfg["min_row"], cfg["max_row"])),
                    "users": U, "items": I, "K": K, "nnz": total_nnz,
                    "parallelism": "1 GPU" if world == 1 else "row-shard x%d (by %s) + RCCL all-reduce(R) per iteration"
