@@ -542,3 +542,22 @@ def test_two_live_plans_sharing_a_run_time_k_kernel(capi, orc):
         orc.factorize(orc.Instance(**d), Lo, Ro, iters=2)
         assert np.array_equal(Lg, Lo) and np.array_equal(Rg, Ro)
         plan.close()
+
+
+@pytest.mark.parametrize("name,iters", [("inst50000-5000-100-2-5", 300), ("inst400-50000-30-200-500", 100),
+                                         ("inst600-10000-10-40-400", 300)])
+def test_bundled_large_samples_factors_bit_exact(capi, orc, name, iters):
+    """The reference's larger samples (users >> items, items >> users, K = 20 / 30 / 10).  Their `.in` files are too
+    big to commit; samples_local/ holds copies when the tree was prepared in the build container (git-ignored) --
+    skipped otherwise.  Factors after `iters` iterations must equal the oracle's bit for bit."""
+    from conftest import ROOT
+    path = os.path.join(ROOT, "samples_local", name + ".in")
+    if not os.path.exists(path):
+        pytest.skip("samples_local/ not present")
+    inst = capi.parse_file(path)
+    L, R = capi.init_factors(inst.users, inst.items, inst.feats)
+    capi.backend_factorize(inst, L, R, iters=iters)
+    oi = orc.parse_in(path)
+    Lo, Ro = orc.init_factors(oi.users, oi.items, oi.feats)
+    orc.factorize(oi, Lo, Ro, iters=iters)
+    assert np.array_equal(L, Lo) and np.array_equal(R, Ro)
