@@ -128,6 +128,10 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the collective even with one rank (rehearsal of the "
                          "RCCL code path on a one-GPU box)")
+    ap.add_argument("--grid", default=None,
+                    help="RxC or 'auto': cut the instance over a 2-D process grid (R user blocks x C item blocks, "
+                         "R*C = --gpus) as matFact-mpi.c does, 'auto' = the reference's create_balanced_grid rule; "
+                         "default: R = --gpus, C = 1 (what that rule picks for cfg4)")
     ap.add_argument("--check", action="store_true",
                     help="after the timed region compare the factors with a single-shard run on rank 0's GPU")
     args = ap.parse_args()
@@ -179,9 +183,22 @@ def main():
     counts, total_nnz = capi.synth_counts(cfg["seed"], U, I, cfg["min_row"], cfg["max_row"])
     ptr = np.zeros(U + 1, np.int64)
     np.cumsum(counts, out=ptr[1:])
-    begin = capi.partition_users(U, world, ptr if args.partition == "entries" else None)
-    u0, uc = int(begin[rank]), int(begin[rank + 1] - begin[rank])
+    grid = (world, 1)
+    if args.grid:
+        grid = capi.balanced_grid(U, I, world) if args.grid == "auto" else tuple(int(x) for x in args.grid.split("x"))
+        if len(grid) != 2 or grid[0] * grid[1] != world:
+            raise SystemExit("--grid %s does not multiply to --gpus %d" % (args.grid, world))
+    gr, gc = rs.sharded.grid_coords(rank, grid)
+    begin = capi.partition_users(U, grid[0], ptr if args.partition == "entries" else None)
+    ibegin = rs.sharded.block_bounds(I, grid[1])
+    u0, uc = int(begin[gr]), int(begin[gr + 1] - begin[gr])
+    j0, ic = int(ibegin[gc]), int(ibegin[gc + 1] - ibegin[gc])
     row, col, val = capi.synth_block(cfg["seed"], U, I, cfg["min_row"], cfg["max_row"], u0, uc)
+    if grid[1] > 1:
+        # this tile's entries, item ids relative to the item block (entries[n].col - offset_col, matFact-mpi.c:193)
+        keep = (col >= j0) & (col < j0 + ic)
+        row, col, val = row[keep], col[keep] - np.int32(j0), val[keep]
+        del keep
     if cfg.get("file"):
         if world != 1:
             raise SystemExit("--config %s: single rank only" % args.config)
@@ -195,17 +212,25 @@ def main():
         total_nnz = int(row.shape[0])
     nnz_loc = int(row.shape[0])
     Lb, R0 = capi.init_factors_block(U, I, K, u0, uc)     # the reference's init rule (mat2d.c:61-72)
-    r_bufs = [torch.empty(I, K, dtype=torch.float64, device=dev) for _ in range(2)]
-    plan = capi.Plan(U, I, K, cfg["alpha"], row, col, val, user_begin=u0, user_count=uc, device=local_dev,
-                     items_ext=[t.data_ptr() for t in r_bufs])
+    r_bufs = [torch.empty(ic, K, dtype=torch.float64, device=dev) for _ in range(2)]
+    l_bufs = [torch.empty(uc, K, dtype=torch.float64, device=dev) for _ in range(2)] if grid[1] > 1 else None
+    plan = capi.Plan(U, ic, K, cfg["alpha"], row, col, val, user_begin=u0, user_count=uc, device=local_dev,
+                     items_ext=[t.data_ptr() for t in r_bufs],
+                     users_ext=[t.data_ptr() for t in l_bufs] if l_bufs else None)
     del row, col, val
     # one explicit stream carries the sweeps AND the collective (the default stream's handle 0 means
     # "plan's own stream" to mf_plan_set_stream, which the collective would not be ordered against)
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
-    run = rs.sharded.ShardedFactorization(plan, r_bufs, rank, world, overlap=not args.no_overlap, stream=stream,
-                                          force_collective=args.force_dist)
-    plan.upload(Lb, R0)
+    if grid[1] > 1:
+        kw = {"backend": "gloo"} if args.backend == "gloo" else {}
+        row_group, col_group = rs.sharded.make_grid_groups(grid, rank, **kw)
+        run = rs.sharded.GridFactorization(plan, l_bufs, r_bufs, rank, grid, row_group, col_group,
+                                           overlap=not args.no_overlap, stream=stream)
+    else:
+        run = rs.sharded.ShardedFactorization(plan, r_bufs, rank, world, overlap=not args.no_overlap, stream=stream,
+                                              force_collective=args.force_dist)
+    plan.upload(Lb, R0[j0:j0 + ic])
     del Lb, R0
     t_setup = time.time() - t_setup
 
@@ -235,7 +260,7 @@ def main():
     # ---- roofline of the dominant kernel (the sweep kernel; item and user sweeps are the same kernel)
     launches = tm["item_launches"] + tm["user_launches"]
     avg_ms = (tm["item_ms"] + tm["user_ms"]) / max(launches, 1)
-    bytes_item = algorithmic_bytes(nnz_loc, K, I)
+    bytes_item = algorithmic_bytes(nnz_loc, K, ic)
     bytes_user = algorithmic_bytes(nnz_loc, K, uc)
     bytes_per_launch = (bytes_item * tm["item_launches"] + bytes_user * tm["user_launches"]) / max(launches, 1)
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -267,8 +292,11 @@ def main():
                                   "power-law rows and item popularity" if args.skew else
                                   "rows %d..%d entries, uniform columns" % (cfg["min_row"], cfg["max_row"])),
                    "users": U, "items": I, "K": K, "nnz": total_nnz,
-                   "parallelism": "1 GPU" if world == 1 else "row-shard x%d (by %s) + RCCL all-reduce(R) per iteration"
-                                  % (world, args.partition)},
+                   "parallelism": "1 GPU" if world == 1 else
+                                  "row-shard x%d (by %s) + RCCL all-reduce(R) per iteration" % (world, args.partition)
+                                  if grid[1] == 1 else
+                                  "%dx%d grid of (user block x item block) tiles + RCCL all-reduce(R) over grid columns, "
+                                  "all-reduce(L) over grid rows per iteration" % grid},
         "roofline": roofline, "setup_s": t_setup,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -279,7 +307,8 @@ def main():
     if args.recommend:
         fence()
         t0 = time.perf_counter()
-        best = run.gather_recommendations(U, begin)
+        best = (run.gather_recommendations(U, begin, ibegin) if grid[1] > 1 else
+                run.gather_recommendations(U, begin))
         fence()
         rs_ = time.perf_counter() - t0
         out["recommend"] = {"seconds": rs_, "flop": 2.0 * U * I * K, "tflops": 2.0 * U * I * K / rs_ / 1e12,
@@ -293,6 +322,13 @@ def main():
             dist.all_gather_object(Lparts, mine)
         else:
             Lparts = [mine]
+        Lparts = [Lparts[r * grid[1]] for r in range(grid[0])]
+        Rmine = run.current_items().cpu().numpy()
+        Rparts = [Rmine]
+        if grid[1] > 1:
+            Rparts = [None] * world
+            dist.all_gather_object(Rparts, Rmine)
+            Rparts = Rparts[:grid[1]]
         if rank == 0:
             row, col, val = capi.synth_block(cfg["seed"], U, I, cfg["min_row"], cfg["max_row"])
             L0, R0 = capi.init_factors(U, I, K)
@@ -300,13 +336,19 @@ def main():
             ref.upload(L0, R0)
             ref.iterate(args.warmup + args.steps)
             Lr, Rr = ref.download()
+            best_ref = ref.recommend() if args.recommend else None
             ref.close()
-            Rs = run.current_items().cpu().numpy()
+            Rs = np.concatenate(Rparts)
             Ls = np.concatenate(Lparts)
             def rel(a, b):
                 return float(np.max(np.abs(a - b) / (np.abs(b) + 1e-300)))
             out["check"] = {"L_max_rel": rel(Ls, Lr), "R_max_rel": rel(Rs, Rr),
                             "L_bit_identical": bool(np.array_equal(Ls, Lr)), "R_bit_identical": bool(np.array_equal(Rs, Rr))}
+            if args.recommend:
+                # the sharded factors differ from the single-shard ones in the last bits, so a near-tie may
+                # legitimately resolve differently; report both the equality and the number of differing users
+                out["check"]["recommend_equal"] = bool(np.array_equal(best, best_ref))
+                out["check"]["recommend_differs"] = int((best != best_ref).sum())
     if rank == 0:
         print(json.dumps(out), flush=True)
     plan.close()

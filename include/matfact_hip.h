@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MATFACT_HIP_ABI_VERSION 1
+#define MATFACT_HIP_ABI_VERSION 2   /* 2: mf_shard.users_ext, seeded user sweep, scored recommend (2-D tiles) */
 
 /* == non_zero_entry, datatypes.h:10-15: the (user, item, rating) triple, 16 bytes, array-of-structs */
 typedef struct mf_entry {
@@ -105,7 +105,15 @@ typedef struct mf_shard {
 	int32_t flags;           /* MF_PLAN_* bits                                           */
 	void *items_ext[2];      /* optional caller-owned DEVICE buffers (items*features doubles each) for the
 	                            two generations of R, e.g. torch tensors handed to a collective; NULL = own */
+	void *users_ext[2];      /* the same for the two generations of this shard's L block (user_count*features
+	                            doubles each); only a 2-D tile needs them (L summed over the grid row) */
 } mf_shard;
+
+/* A TILE of the reference's 2-D process grid (matFact-mpi.c:155-214, grid from create_balanced_grid,
+ * mpiutil.c:54-88) is a shard that also holds only a block of the items: the caller passes `items` = the
+ * block's item count and `col` relative to the block's first item (entries[n].col - offset_col,
+ * matFact-mpi.c:193), exactly as user ids are relative to user_begin inside the plan.  Item indices that
+ * mf_plan_recommend* return are then block-relative too. */
 
 #define MF_PLAN_DEFAULT 0
 #define MF_PLAN_RELAXED_ORDER 1   /* reserved: allow re-associated sums (tolerance mode) */
@@ -135,6 +143,14 @@ void *mf_plan_items_next(mf_plan *plan);     /* device pointer, items*features d
 void *mf_plan_items_current(mf_plan *plan);
 int mf_plan_flip(mf_plan *plan);
 
+/* 2-D tiles: the L block is shared by the ranks of a grid row and summed over them like R is over a grid
+ * column (the two MPI_Iallreduce of matFact-mpi.c:207-208) --
+ *   mf_plan_sweep_users_seeded: L_next = (seed_from_old ? L_cur : 0) + sum over LOCAL entries  (:188)
+ *   caller SUM-all-reduces mf_plan_users_next() over the grid row, mf_plan_items_next() over the grid column. */
+int mf_plan_sweep_users_seeded(mf_plan *plan, int seed_from_old);
+void *mf_plan_users_next(mf_plan *plan);     /* device pointer, user_count*features doubles */
+void *mf_plan_users_current(mf_plan *plan);
+
 /* Recommendations for this shard's users against the current R; best has user_count entries.
  * Default form: scores on the FP64 matrix cores (MFMA), every user whose best/second-best margin is not
  * provably larger than the rounding bound re-scored in the reference's exact order, so the result is the
@@ -142,6 +158,24 @@ int mf_plan_flip(mf_plan *plan);
 int mf_plan_recommend(mf_plan *plan, int32_t *best);
 /* users the last mf_plan_recommend sent through the exact pass (-1 when the exact form ran for all) */
 int mf_plan_recommend_info(mf_plan *plan, int64_t *exact_pass_users);
+
+/* Partial result of the sequential scan of print_output (matFact.c:13-23) over this plan's items, in a form
+ * that can be combined over the item blocks of a grid row (what MPI_Reduce(max_cmp) does at matFact-mpi.c:98):
+ * the scan keeps the FIRST unrated item until a strictly greater score appears, and a NaN score never compares
+ * greater, so per user the partial state is
+ *   best/score  arg-max and max over the unrated items with a non-NaN score, lowest index on ties (-1: none),
+ *               score being the reference's B[i][j] bit for bit (sequential k, unfused);
+ *   first       the first unrated item (-1: every item rated);  first_nan  its score is NaN.
+ * Combining blocks left to right: first = the first block's that has one; best = the greater score, the earlier
+ * block on ties; answer = first < 0 ? -1 : first_nan ? first : best.  Exact form for every user. */
+typedef struct mf_candidate {
+	double score;
+	int32_t best;
+	int32_t first;
+	int32_t first_nan;
+	int32_t reserved;
+} mf_candidate;
+int mf_plan_recommend_scored(mf_plan *plan, mf_candidate *out);   /* user_count entries */
 
 /* Dense predictions of this shard's users, B (user_count x items, row-major) = L R^T exactly as mat2d_prod
  * (mat2d.c:100-113) forms them; for debug dumps of SMALL instances (user_count*items <= 2^26). */

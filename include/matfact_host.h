@@ -10,6 +10,7 @@
  *   mf_host_block_*         BLOCK_LOW/HIGH/SIZE/OWNER mpiutil.h:8-13
  *   mf_host_partition_users contiguous user blocks for P shards, by row count (the reference's rule)
  *                           or balanced by entry count
+ *   mf_host_balanced_grid   rows x cols of the 2-D process grid       mpiutil.c:54-88 (create_balanced_grid)
  *   mf_host_write_out       the `.out` writer         matFact.c:24-25
  *   mf_host_synth_*         deterministic synthetic instances (the reference ships no generator;
  *                           SURVEY.md section 8d defines the shapes)
@@ -72,6 +73,13 @@ static inline int mf_host_block_owner(int64_t index, int p, int64_t n) { return 
 /* begin[0..parts]: user boundaries.  by_entries = 0: BLOCK_LOW rule; 1: cut at row boundaries so that each
  * part holds about nnz/parts entries (row_ptr = CSR row pointer of the whole instance, users+1 long). */
 int mf_host_partition_users(int users, int parts, int by_entries, const int64_t *row_ptr, int32_t *begin);
+
+/* The process grid of the MPI variant (create_balanced_grid, mpiutil.c:54-88): size[0] grid rows (user blocks)
+ * x size[1] grid columns (item blocks), size[0]*size[1] == nproc.  Starts from the most square factorisation
+ * (what MPI_Dims_create gives two free dimensions, larger first) and moves prime factors to the long side while
+ * it stays <= min(nproc, long/short aspect ratio of the matrix); the long side of the grid is laid along the
+ * long side of the matrix.  cfg4 (1e6 x 1e5) on 8 ranks: 8x1; a square matrix: 4x2. */
+int mf_host_balanced_grid(int users, int items, int nproc, int32_t size[2]);
 
 /* one line per user with best >= 0 */
 int mf_host_write_out(FILE *f, const int32_t *best, int users);

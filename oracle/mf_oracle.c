@@ -19,6 +19,8 @@
  *                         (CPU baseline, `cpu_baseline.kind = "port"`)
  *   orc_shard_step     <- one iteration of the MPI block update (matFact-mpi.c:185-210) for a
  *                         row shard: aux = (root ? old : 0) + local sums; the caller SUM-reduces.
+ *   orc_tile_step      <- the same for one tile (user block x item block) of the 2-D process grid:
+ *                         both factors start from old on their communicator's root only (:187-188).
  *
  * Parity pin: checked against the reference itself (oracle/_ref, built from the reference's own
  * sources by oracle/Makefile) on every bundled sample and against the bundled samples' .out files
@@ -147,6 +149,33 @@ void orc_shard_step(int u0, int users_loc, int items, int feats, int64_t nnz_loc
 		const double *rs = R_old + (int64_t) col[n] * feats;
 		double *l = L_new + i * feats;
 		double *r = R_aux + (int64_t) col[n] * feats;
+		const double e = alpha * 2 * (val[n] - seq_dot(ls, rs, feats));
+		for (int k = 0; k < feats; k++) {
+			l[k] = l[k] - e * (-rs[k]);
+			r[k] = r[k] - e * (-ls[k]);
+		}
+	}
+}
+
+/*
+ * One iteration of the block update for a TILE of the 2-D grid (matFact-mpi.c:185-205): users
+ * [u0, u0+users_loc) x items [j0, j0+items_loc), row[]/col[] GLOBAL ids of the entries inside the tile.
+ * L_aux starts from L_old on the row communicator's root and R_aux from R_old on the column communicator's
+ * root, from zero elsewhere (:187-188); the caller SUM-reduces L_aux over the grid row and R_aux over the
+ * grid column (:207-208).
+ */
+void orc_tile_step(int u0, int users_loc, int j0, int items_loc, int feats, int64_t nnz_loc,
+                   const int32_t *row, const int32_t *col, const double *val, double alpha,
+                   const double *L_old, const double *R_old, int l_is_root, int r_is_root,
+                   double *L_aux, double *R_aux)
+{
+	const size_t nl = sizeof(double) * (size_t) users_loc * feats, nr = sizeof(double) * (size_t) items_loc * feats;
+	if (l_is_root) memcpy(L_aux, L_old, nl); else memset(L_aux, 0, nl);
+	if (r_is_root) memcpy(R_aux, R_old, nr); else memset(R_aux, 0, nr);
+	for (int64_t n = 0; n < nnz_loc; n++) {
+		const int64_t i = row[n] - u0, j = col[n] - j0;
+		const double *ls = L_old + i * feats, *rs = R_old + j * feats;
+		double *l = L_aux + i * feats, *r = R_aux + j * feats;
 		const double e = alpha * 2 * (val[n] - seq_dot(ls, rs, feats));
 		for (int k = 0; k < feats; k++) {
 			l[k] = l[k] - e * (-rs[k]);

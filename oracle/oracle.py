@@ -55,6 +55,9 @@ def _lib(o3=False):
         lib.orc_shard_step.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _i32p, _i32p, _f64p,
                                        C.c_double, _f64p, _f64p, C.c_int, _f64p, _f64p]
         lib.orc_shard_step.restype = None
+        lib.orc_tile_step.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _i32p, _i32p, _f64p,
+                                      C.c_double, _f64p, _f64p, C.c_int, C.c_int, _f64p, _f64p]
+        lib.orc_tile_step.restype = None
         lib.orc_set_threads.argtypes = [C.c_int]
         lib.orc_set_threads.restype = None
         _libs[name] = lib
@@ -136,6 +139,15 @@ def shard_step(u0, users_loc, items, feats, row, col, val, alpha, L_old, R_old, 
     _lib().orc_shard_step(u0, users_loc, items, feats, int(row.shape[0]), row, col, val, alpha,
                           L_old, R_old, int(bool(r_is_root)), L_new, R_aux)
     return L_new, R_aux
+
+
+def tile_step(u0, users_loc, j0, items_loc, feats, row, col, val, alpha, L_old, R_old, l_is_root, r_is_root):
+    """One iteration of a 2-D grid tile (matFact-mpi.c:185-205); row/col are global ids inside the tile."""
+    L_aux = np.empty_like(L_old)
+    R_aux = np.empty_like(R_old)
+    _lib().orc_tile_step(u0, users_loc, j0, items_loc, feats, int(row.shape[0]), row, col, val, alpha,
+                         L_old, R_old, int(bool(l_is_root)), int(bool(r_is_root)), L_aux, R_aux)
+    return L_aux, R_aux
 
 
 def run(inst):

@@ -30,13 +30,14 @@ HIP_SYMBOLS = [
     "mf_plan_create", "mf_plan_destroy", "mf_plan_set_stream", "mf_plan_upload_factors",
     "mf_plan_download_factors", "mf_plan_iterate", "mf_plan_sweep_items", "mf_plan_sweep_users",
     "mf_plan_items_next", "mf_plan_items_current", "mf_plan_flip", "mf_plan_recommend", "mf_plan_recommend_info",
+    "mf_plan_sweep_users_seeded", "mf_plan_users_next", "mf_plan_users_current", "mf_plan_recommend_scored",
     "mf_plan_predict", "mf_plan_synchronize",
     "mf_plan_timing", "mf_plan_timing_read", "mf_plan_describe",
 ]
 HOST_SYMBOLS = [
     "mf_host_parse_strerror", "mf_host_parse_file", "mf_host_parse_buffer", "mf_host_free_problem",
     "mf_host_srandom", "mf_host_random", "mf_host_init_factors", "mf_host_init_factors_block",
-    "mf_host_split_entries", "mf_host_partition_users", "mf_host_write_out", "mf_host_checkpoint_write",
+    "mf_host_split_entries", "mf_host_partition_users", "mf_host_balanced_grid", "mf_host_write_out", "mf_host_checkpoint_write",
     "mf_host_checkpoint_read", "mf_host_synth_counts",
     "mf_host_synth_fill",
 ]
@@ -63,7 +64,13 @@ class Shard(C.Structure):  # mf_shard
     _fields_ = [("users_total", C.c_int32), ("items", C.c_int32), ("features", C.c_int32),
                 ("user_begin", C.c_int32), ("user_count", C.c_int32), ("nnz", C.c_int64),
                 ("row", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p), ("alpha", C.c_double),
-                ("device", C.c_int32), ("flags", C.c_int32), ("items_ext", C.c_void_p * 2)]
+                ("device", C.c_int32), ("flags", C.c_int32), ("items_ext", C.c_void_p * 2),
+                ("users_ext", C.c_void_p * 2)]
+
+
+# mf_candidate: the partial scan state of mf_plan_recommend_scored, as a numpy record layout
+CANDIDATE_DTYPE = np.dtype([("score", np.float64), ("best", np.int32), ("first", np.int32),
+                            ("first_nan", np.int32), ("reserved", np.int32)])
 
 
 class Synth(C.Structure):  # mf_synth
@@ -109,6 +116,12 @@ def hip():
         lib.mf_plan_items_current.argtypes = [P]
         lib.mf_plan_items_current.restype = P
         lib.mf_plan_flip.argtypes = [P]
+        lib.mf_plan_sweep_users_seeded.argtypes = [P, C.c_int]
+        lib.mf_plan_users_next.argtypes = [P]
+        lib.mf_plan_users_next.restype = P
+        lib.mf_plan_users_current.argtypes = [P]
+        lib.mf_plan_users_current.restype = P
+        lib.mf_plan_recommend_scored.argtypes = [P, P]
         lib.mf_plan_recommend.argtypes = [P, _i32p]
         lib.mf_plan_recommend_info.argtypes = [P, C.POINTER(C.c_int64)]
         lib.mf_plan_predict.argtypes = [P, _f64p]
@@ -144,6 +157,7 @@ def host():
         lib.mf_host_split_entries.argtypes = [C.POINTER(Entry), C.c_int64, _i32p, _i32p, _f64p]
         lib.mf_host_split_entries.restype = None
         lib.mf_host_partition_users.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, _i32p]
+        lib.mf_host_balanced_grid.argtypes = [C.c_int, C.c_int, C.c_int, _i32p]
         lib.mf_host_synth_counts.argtypes = [C.POINTER(Synth), C.c_int, C.c_int, _i32p]
         lib.mf_host_synth_counts.restype = C.c_int64
         lib.mf_host_synth_fill.argtypes = [C.POINTER(Synth), C.c_int, C.c_int, _i32p, _i32p, _i32p, _f64p]
@@ -239,6 +253,14 @@ def partition_users(users, parts, row_ptr=None):
     return begin
 
 
+def balanced_grid(users, items, nproc):
+    """(grid rows, grid cols) of the reference's 2-D process grid (create_balanced_grid, mpiutil.c:54-88)."""
+    size = np.empty(2, np.int32)
+    if host().mf_host_balanced_grid(int(users), int(items), int(nproc), size) != 0:
+        raise ValueError("mf_host_balanced_grid failed")
+    return int(size[0]), int(size[1])
+
+
 def synth_counts(seed, users, items, min_row, max_row, u0=0, count=None):
     count = users - u0 if count is None else count
     s = Synth(seed, users, items, min_row, max_row)
@@ -308,7 +330,7 @@ class Plan:
     """mf_plan: one shard resident on one GPU."""
 
     def __init__(self, users_total, items, feats, alpha, row, col, val, user_begin=0, user_count=None,
-                 device=0, items_ext=None, flags=0):
+                 device=0, items_ext=None, flags=0, users_ext=None):
         self.users_total, self.items, self.feats = int(users_total), int(items), int(feats)
         self.user_begin = int(user_begin)
         self.user_count = int(users_total - user_begin if user_count is None else user_count)
@@ -322,6 +344,8 @@ class Plan:
         s.alpha, s.device, s.flags = float(alpha), int(device), int(flags)
         if items_ext is not None:
             s.items_ext[0], s.items_ext[1] = int(items_ext[0]), int(items_ext[1])
+        if users_ext is not None:
+            s.users_ext[0], s.users_ext[1] = int(users_ext[0]), int(users_ext[1])
         self.nnz = s.nnz
         self._h = C.c_void_p()
         _check(hip().mf_plan_create(C.byref(self._h), C.byref(s)), "mf_plan_create")
@@ -356,8 +380,14 @@ class Plan:
     def sweep_items(self, seed_from_old=True):
         _check(hip().mf_plan_sweep_items(self._h, 1 if seed_from_old else 0), "mf_plan_sweep_items")
 
-    def sweep_users(self):
-        _check(hip().mf_plan_sweep_users(self._h), "mf_plan_sweep_users")
+    def sweep_users(self, seed_from_old=True):
+        _check(hip().mf_plan_sweep_users_seeded(self._h, 1 if seed_from_old else 0), "mf_plan_sweep_users_seeded")
+
+    def users_next_ptr(self):
+        return hip().mf_plan_users_next(self._h)
+
+    def users_current_ptr(self):
+        return hip().mf_plan_users_current(self._h)
 
     def items_next_ptr(self):
         return hip().mf_plan_items_next(self._h)
@@ -372,6 +402,12 @@ class Plan:
         best = np.empty(self.user_count, np.int32)
         _check(hip().mf_plan_recommend(self._h, best), "mf_plan_recommend")
         return best
+
+    def recommend_scored(self):
+        """Partial scan state per user (CANDIDATE_DTYPE records); item ids relative to this plan's item block."""
+        out = np.zeros(self.user_count, CANDIDATE_DTYPE)
+        _check(hip().mf_plan_recommend_scored(self._h, out.ctypes.data), "mf_plan_recommend_scored")
+        return out
 
     def recommend_info(self):
         n = C.c_int64()

@@ -64,6 +64,9 @@ int mf_plan_create(mf_plan **out, const mf_shard *s)
 	if ((s->items_ext[0] == nullptr) != (s->items_ext[1] == nullptr) || ((uintptr_t) s->items_ext[0] & 15) ||
 	    ((uintptr_t) s->items_ext[1] & 15) || (s->items_ext[0] && s->items_ext[0] == s->items_ext[1]))
 		return MF_ERR_ARGUMENT;
+	if ((s->users_ext[0] == nullptr) != (s->users_ext[1] == nullptr) || ((uintptr_t) s->users_ext[0] & 15) ||
+	    ((uintptr_t) s->users_ext[1] & 15) || (s->users_ext[0] && s->users_ext[0] == s->users_ext[1]))
+		return MF_ERR_ARGUMENT;
 	const int ndev = mf_backend_device_count();
 	if (ndev <= 0 || s->device < 0 || s->device >= ndev) return MF_ERR_NO_DEVICE;
 	MF_HIP(hipSetDevice(s->device));
@@ -110,8 +113,14 @@ int mf_plan_create(mf_plan **out, const mf_shard *s)
 	}
 
 	const size_t nl = (size_t) p->uc * p->K, nr = (size_t) p->items * p->K;
-	MF_TRY(dev_alloc(&p->Lbuf[0], nl));
-	MF_TRY(dev_alloc(&p->Lbuf[1], nl));
+	if (s->users_ext[0] && s->users_ext[1]) {
+		p->l_external = true;
+		p->Lbuf[0] = (double *) s->users_ext[0];
+		p->Lbuf[1] = (double *) s->users_ext[1];
+	} else {
+		MF_TRY(dev_alloc(&p->Lbuf[0], nl));
+		MF_TRY(dev_alloc(&p->Lbuf[1], nl));
+	}
 	if (s->items_ext[0] && s->items_ext[1]) {
 		p->r_external = true;
 		p->Rbuf[0] = (double *) s->items_ext[0];
@@ -146,8 +155,11 @@ void mf_plan_destroy(mf_plan *p)
 	(void) hipFree(p->csc_ptr);
 	(void) hipFree(p->csc_idx);
 	(void) hipFree(p->csc_val);
-	(void) hipFree(p->Lbuf[0]);
-	(void) hipFree(p->Lbuf[1]);
+	if (!p->l_external) {
+		(void) hipFree(p->Lbuf[0]);
+		(void) hipFree(p->Lbuf[1]);
+	}
+	(void) hipFree(p->cand_dev);
 	if (!p->r_external) {
 		(void) hipFree(p->Rbuf[0]);
 		(void) hipFree(p->Rbuf[1]);
@@ -216,16 +228,20 @@ int mf_plan_sweep_items(mf_plan *p, int seed_from_old)
 	return launch_sweep(p, 0, seed_from_old ? 1 : 0);
 }
 
-int mf_plan_sweep_users(mf_plan *p)
+int mf_plan_sweep_users_seeded(mf_plan *p, int seed_from_old)
 {
 	if (!p) return MF_ERR_ARGUMENT;
 	if (!p->have_factors) return MF_ERR_STATE;
 	MF_HIP(hipSetDevice(p->device));
-	return launch_sweep(p, 1, 1);
+	return launch_sweep(p, 1, seed_from_old ? 1 : 0);
 }
+
+int mf_plan_sweep_users(mf_plan *p) { return mf_plan_sweep_users_seeded(p, 1); }
 
 void *mf_plan_items_next(mf_plan *p) { return p ? p->Rbuf[p->cur ^ 1] : nullptr; }
 void *mf_plan_items_current(mf_plan *p) { return p ? p->Rbuf[p->cur] : nullptr; }
+void *mf_plan_users_next(mf_plan *p) { return p ? p->Lbuf[p->cur ^ 1] : nullptr; }
+void *mf_plan_users_current(mf_plan *p) { return p ? p->Lbuf[p->cur] : nullptr; }
 
 int mf_plan_flip(mf_plan *p)
 {
@@ -303,6 +319,7 @@ int mf_plan_recommend(mf_plan *p, int32_t *best)
 	ex.csr_idx = p->csr_idx;
 	ex.best = p->best_dev;
 	ex.ulist = nullptr;
+	ex.cand = nullptr;
 	if (!use_mfma) {
 		const int grid = (p->uc + mf::kRT - 1) / mf::kRT;
 		hipLaunchKernelGGL(mf::recommend_kernel, dim3(grid), dim3(256), 0, p->stream, ex);
@@ -351,6 +368,34 @@ int mf_plan_recommend(mf_plan *p, int32_t *best)
 		}
 	}
 	MF_HIP(hipMemcpyAsync(best, p->best_dev, (size_t) p->uc * sizeof(int), hipMemcpyDeviceToHost, p->stream));
+	MF_HIP(hipStreamSynchronize(p->stream));
+	return MF_OK;
+}
+
+int mf_plan_recommend_scored(mf_plan *p, mf_candidate *out)
+{
+	if (!p || (!out && p->uc > 0)) return MF_ERR_ARGUMENT;
+	if (!p->have_factors) return MF_ERR_STATE;
+	MF_HIP(hipSetDevice(p->device));
+	if (p->uc == 0) return MF_OK;
+	if (!p->cand_dev) {
+		const int rc = dev_alloc(&p->cand_dev, (size_t) p->uc);
+		if (rc != MF_OK) return rc;
+	}
+	mf::RecArgs ex;
+	ex.users = p->uc;
+	ex.items = p->items;
+	ex.K = p->K;
+	ex.L = p->Lbuf[p->cur];
+	ex.R = p->Rbuf[p->cur];
+	ex.csr_ptr = p->csr_ptr;
+	ex.csr_idx = p->csr_idx;
+	ex.best = p->best_dev;
+	ex.ulist = nullptr;
+	ex.cand = p->cand_dev;
+	hipLaunchKernelGGL(mf::recommend_kernel, dim3((p->uc + mf::kRT - 1) / mf::kRT), dim3(256), 0, p->stream, ex);
+	MF_HIP(hipGetLastError());
+	MF_HIP(hipMemcpyAsync(out, p->cand_dev, (size_t) p->uc * sizeof(mf_candidate), hipMemcpyDeviceToHost, p->stream));
 	MF_HIP(hipStreamSynchronize(p->stream));
 	return MF_OK;
 }

@@ -109,6 +109,8 @@ struct mf_plan {
 	double *Lbuf[2] = {nullptr, nullptr};
 	double *Rbuf[2] = {nullptr, nullptr};
 	bool r_external = false;
+	bool l_external = false;
+	mf_candidate *cand_dev = nullptr;   // recommend_scored output, allocated on first use
 	int cur = 0;            // generation index of the current factors
 	bool have_factors = false;
 	int *best_dev = nullptr;

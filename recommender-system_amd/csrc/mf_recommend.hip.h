@@ -2,6 +2,7 @@
 // dense predictions for the debug dump.
 #pragma once
 #include "mf_common.hip.h"
+#include "../../include/matfact_hip.h"   // mf_candidate
 
 namespace mf {
 // ------------------------------------------------------------------------------------------------
@@ -21,6 +22,7 @@ struct RecArgs {
 	const int *__restrict__ csr_idx; // item ids, ascending within a user
 	int *__restrict__ best;          // users
 	const int *__restrict__ ulist;   // optional: only these users (indices into the shard), `users` = its length
+	mf_candidate *__restrict__ cand; // optional: the partial scan state per user (2-D tiles combine it over item blocks)
 };
 
 struct Cand {
@@ -161,9 +163,11 @@ __global__ void __launch_bounds__(256) recommend_kernel(RecArgs a)
 #pragma unroll
 		for (int u = 0; u < 4; ++u) {
 			const int i = i0 + ty * 4 + u;
-			if (i < a.users)
-				a.best[a.ulist ? a.ulist[i] : i] =
-				    run[u].first < 0 ? -1 : (run[u].fnan ? run[u].first : run[u].bi);
+			if (i < a.users) {
+				const int uid = a.ulist ? a.ulist[i] : i;
+				a.best[uid] = run[u].first < 0 ? -1 : (run[u].fnan ? run[u].first : run[u].bi);
+				if (a.cand) a.cand[uid] = mf_candidate{run[u].bv, run[u].bi, run[u].first, run[u].fnan, 0};
+			}
 		}
 	}
 }

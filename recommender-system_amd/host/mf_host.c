@@ -372,6 +372,37 @@ int mf_host_partition_users(int users, int parts, int by_entries, const int64_t 
 	return 0;
 }
 
+static int least_prime_factor(int n)
+{
+	for (int d = 2; (int64_t) d * d <= n; d++)
+		if (n % d == 0) return d;
+	return n;
+}
+
+int mf_host_balanced_grid(int users, int items, int nproc, int32_t size[2])
+{
+	if (nproc < 1 || users < 0 || items < 0 || !size) return -1;
+	/* most square factorisation, larger factor first */
+	int small = 1;
+	for (int d = 1; (int64_t) d * d <= nproc; d++)
+		if (nproc % d == 0) small = d;
+	int along = nproc / small, across = small;   /* along = the side that follows the longer matrix dimension */
+	const int longer = users > items ? users : items, shorter = users > items ? items : users;
+	const int ratio = shorter > 0 ? longer / shorter : 1;
+	if (ratio > 1) {
+		const int limit = nproc < ratio ? nproc : ratio;
+		while (along < limit && across > 1) {
+			const int f = least_prime_factor(across);
+			if ((int64_t) along * f > limit) break;
+			along *= f;
+			across /= f;
+		}
+	}
+	size[0] = items > users ? across : along;
+	size[1] = items > users ? along : across;
+	return 0;
+}
+
 int mf_host_write_out(FILE *f, const int32_t *best, int users)
 {
 	for (int i = 0; i < users; i++)

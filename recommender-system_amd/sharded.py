@@ -89,3 +89,141 @@ class ShardedFactorization:
         for g in range(self.world):
             out[begin[g]:begin[g + 1]] = parts[g]
         return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# 2-D process grid: the full decomposition of matFact-mpi.c:155-214.  Rank (gr, gc) of a
+# rows x cols grid (create_balanced_grid, mpiutil.c:54-88 -> capi.balanced_grid; rank = gr*cols + gc, the
+# row-major order of MPI_Cart_create) owns the TILE user block gr x item block gc: its entries, a copy of the
+# L block (shared by the ranks of grid row gr) and of the R block (shared by the ranks of grid column gc).
+# Per iteration (matFact-mpi.c:185-209)
+#     item sweep : R_next = (gr == 0 ? R_cur : 0) + sum over the tile's entries     :187, :190-205
+#     all-reduce : R_next over the grid COLUMN (ranks with the same gc)             :208  (col_comm)
+#     user sweep : L_next = (gc == 0 ? L_cur : 0) + sum over the tile's entries     :188
+#     all-reduce : L_next over the grid ROW (ranks with the same gr)                :207  (row_comm)
+#     flip
+# With cols == 1 this is the row-sharded scheme above; with rows == 1 its mirror image (item-heavy inputs).
+# Recommendation: every tile scans its own item block (mf_plan_recommend_scored), the partial scan states are
+# combined left to right over the item blocks -- the MPI_Reduce(max_cmp) of matFact-mpi.c:98, with the serial
+# program's tie and NaN rules (matFact.c:13-23) instead of the MPI variant's.
+# ------------------------------------------------------------------------------------------------------------
+def grid_coords(rank, grid):
+    return rank // grid[1], rank % grid[1]
+
+
+def block_bounds(n, parts):
+    """BLOCK_LOW boundaries (mpiutil.h:8) of n indices over `parts` blocks."""
+    return np.array([(p * n) // parts for p in range(parts + 1)], np.int64)
+
+
+def make_grid_groups(grid, rank, **new_group_kwargs):
+    """(row_group, col_group) of this rank; every rank must call it (dist.new_group is collective).
+    row_group joins the ranks of one grid row (they share an L block), col_group those of one grid column."""
+    rows, cols = grid
+    row_group = col_group = None
+    for gr in range(rows):
+        ranks = [gr * cols + c for c in range(cols)]
+        g = dist.new_group(ranks, **new_group_kwargs) if cols > 1 else None
+        if rank in ranks:
+            row_group = g
+    for gc in range(cols):
+        ranks = [r * cols + gc for r in range(rows)]
+        g = dist.new_group(ranks, **new_group_kwargs) if rows > 1 else None
+        if rank in ranks:
+            col_group = g
+    return row_group, col_group
+
+
+def merge_candidates(left, right):
+    """Combine the partial scan states (capi.CANDIDATE_DTYPE records, GLOBAL item ids) of two item ranges,
+    `left` holding the lower item ids: what the sequential scan of matFact.c:13-23 would hold after both."""
+    out = left.copy()
+    no_first = left["first"] < 0
+    out["first"][no_first] = right["first"][no_first]
+    out["first_nan"][no_first] = right["first_nan"][no_first]
+    take = (right["best"] >= 0) & ((left["best"] < 0) | (right["score"] > left["score"]))
+    out["best"][take] = right["best"][take]
+    out["score"][take] = right["score"][take]
+    return out
+
+
+def finish_candidates(c):
+    """best[i] of print_output: -1 without an unrated item; the first unrated item when its score is NaN
+    (nothing compares greater than NaN); else the arg-max over the non-NaN scores."""
+    return np.where(c["first"] < 0, -1, np.where(c["first_nan"] != 0, c["first"], c["best"])).astype(np.int32)
+
+
+class GridFactorization:
+    """Iterations of one tile of the rows x cols grid; both factor generations live in torch tensors."""
+
+    def __init__(self, plan, l_buffers, r_buffers, rank, grid, row_group=None, col_group=None, overlap=True,
+                 stream=None):
+        self.plan, self.rank, self.grid, self.overlap = plan, rank, tuple(grid), overlap
+        self.gr, self.gc = grid_coords(rank, grid)
+        self.row_group, self.col_group = row_group, col_group
+        self.l, self.r = list(l_buffers), list(r_buffers)
+        self._ptr = {int(t.data_ptr()): t for t in self.l + self.r}
+        self.stream = stream
+        if stream is not None:
+            if int(stream.cuda_stream) == 0:
+                raise ValueError("GridFactorization needs a non-default CUDA stream")
+            plan.set_stream(int(stream.cuda_stream))
+        elif self.r[0].is_cuda:
+            raise ValueError("GPU buffers need an explicit stream")
+        if self.grid[1] > 1 and row_group is None or self.grid[0] > 1 and col_group is None:
+            raise ValueError("a %dx%d grid needs its row and column process groups" % self.grid)
+
+    def current_items(self):
+        return self._ptr[int(self.plan.items_current_ptr())]
+
+    def current_users(self):
+        return self._ptr[int(self.plan.users_current_ptr())]
+
+    def step(self):
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                self._step()
+        else:
+            self._step()
+
+    def _step(self):
+        p = self.plan
+        rows, cols = self.grid
+        pending = []
+        p.sweep_items(self.gr == 0)
+        if rows > 1:
+            nxt = self._ptr[int(p.items_next_ptr())]
+            pending.append(dist.all_reduce(nxt, op=dist.ReduceOp.SUM, group=self.col_group, async_op=True))
+            if not self.overlap:
+                pending.pop().wait()
+        p.sweep_users(self.gc == 0)
+        if cols > 1:
+            nxt = self._ptr[int(p.users_next_ptr())]
+            pending.append(dist.all_reduce(nxt, op=dist.ReduceOp.SUM, group=self.row_group, async_op=True))
+        for w in pending:
+            w.wait()
+        p.flip()
+
+    def run(self, iters):
+        for _ in range(iters):
+            self.step()
+
+    def gather_recommendations(self, users_total, user_begin, item_begin):
+        """Every tile scans its item block; the states of a grid row are merged in item order and the user
+        blocks concatenated.  Every rank returns the full list (small: one int per user)."""
+        world = self.grid[0] * self.grid[1]
+        cand = self.plan.recommend_scored()
+        j0 = int(item_begin[self.gc])
+        for f in ("best", "first"):
+            cand[f][cand[f] >= 0] += j0
+        parts = [cand]
+        if world > 1:
+            parts = [None] * world
+            dist.all_gather_object(parts, cand)
+        out = np.empty(users_total, np.int32)
+        for gr in range(self.grid[0]):
+            acc = parts[gr * self.grid[1]]
+            for gc in range(1, self.grid[1]):
+                acc = merge_candidates(acc, parts[gr * self.grid[1] + gc])
+            out[user_begin[gr]:user_begin[gr + 1]] = finish_candidates(acc)
+        return out
