@@ -348,12 +348,32 @@ int mf_plan_recommend(mf_plan *p, int32_t *best)
 		m.best = p->best_dev;
 		m.ulist = p->ulist;
 		m.ucount = p->ucount;
-		if ((p->K & 1) == 0)
-			hipLaunchKernelGGL(mf::recommend_mfma_kernel<true>, dim3((p->uc + mf::kMU - 1) / mf::kMU),
-			                   dim3(mf::kMThreads), 0, p->stream, m);
+		// Form: the L block resident in LDS (it is the same for every item tile; only R chunks are staged) whenever
+		// its image fits beside the two R buffers -- K <= 64 with 32-deep chunks, K = 80 / 100 with 20-deep chunks
+		// (5 x 20 at K=100 instead of 32+32+32+4: no short remainder chunk) -- else both operands staged per chunk.
+		// Measured on 1e6 x 1e5: K=100 48.8 vs 47.7 TFLOP/s, K=64 49.9 vs 46.8, K=30 37.5 vs 34.1.
+		typedef void (*RecFn)(mf::RecMfmaArgs);
+		const bool vec = (p->K & 1) == 0;
+		const char *ares_env = getenv("MF_RECOMMEND_ARES");   // "0" disables the resident-L form (tests, A/B)
+		const bool allow = !(ares_env && ares_env[0] == '0');
+		const size_t static_lds = 8 * 1024, cu_lds = 160 * 1024;   // masks + merge arrays, rounded up
+		int kc = 32;
+		bool ares = false;
+		if (allow && mf::rec_mfma_lds(p->K, 32, true) + static_lds <= cu_lds) {
+			ares = true;
+		} else if (allow && p->K % 20 == 0 && mf::rec_mfma_lds(p->K, 20, true) + static_lds <= cu_lds) {
+			ares = true;
+			kc = 20;
+		}
+		RecFn fn;
+		if (kc == 20)
+			fn = mf::recommend_mfma_kernel<true, 20, true>;   // K % 20 == 0 is even
 		else
-			hipLaunchKernelGGL(mf::recommend_mfma_kernel<false>, dim3((p->uc + mf::kMU - 1) / mf::kMU),
-			                   dim3(mf::kMThreads), 0, p->stream, m);
+			fn = ares ? (vec ? mf::recommend_mfma_kernel<true, 32, true> : mf::recommend_mfma_kernel<false, 32, true>)
+			          : (vec ? mf::recommend_mfma_kernel<true, 32, false> : mf::recommend_mfma_kernel<false, 32, false>);
+		const size_t lds = mf::rec_mfma_lds(p->K, kc, ares);
+		MF_HIP(raise_lds_limit((const void *) fn, lds));
+		hipLaunchKernelGGL(fn, dim3((p->uc + mf::kMU - 1) / mf::kMU), dim3(mf::kMThreads), lds, p->stream, m);
 		MF_HIP(hipGetLastError());
 		int cnt = 0;
 		MF_HIP(hipMemcpyAsync(&cnt, p->ucount, sizeof(int), hipMemcpyDeviceToHost, p->stream));

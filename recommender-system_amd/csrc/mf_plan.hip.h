@@ -21,9 +21,11 @@ using SweepFn = void (*)(mf::SweepArgs);
 inline hipError_t raise_lds_limit(const void *fn, size_t bytes)
 {
 	static std::mutex mu;
-	static std::map<const void *, size_t> limit;
+	static std::map<std::pair<int, const void *>, size_t> limit;   // the attribute is kept per device
 	std::lock_guard<std::mutex> lock(mu);
-	size_t &cur = limit[fn];
+	int dev = 0;
+	(void) hipGetDevice(&dev);
+	size_t &cur = limit[std::make_pair(dev, fn)];
 	if (bytes <= cur) return hipSuccess;
 	const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
 	if (e == hipSuccess) cur = bytes;

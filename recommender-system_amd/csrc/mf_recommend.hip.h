@@ -195,9 +195,9 @@ __global__ void __launch_bounds__(256) predict_kernel(const double *__restrict__
 //          4x margin) the approximate arg-max IS the reference's arg-max and no tie rule is involved.
 //   pass 2 (recommend_kernel with `ulist`)  every other user -- near-ties, exact ties (the lowest index
 //          must win), non-finite scores -- is re-scored in the reference's exact order.
-// Tile: 256 threads = 4 waves (2 x 2) own 128 users x 64 items per step; each wave holds 4 x 2
-// accumulator tiles of 16 x 16 (64 VGPRs); L and R k-chunks of 16 go through LDS stored k-major with a
-// leading dimension that puts the two 16-lane halves of a ds_read_b64 group on disjoint banks.
+// Tile: 512 threads = 8 waves (4 x 2) own 128 users x 128 items per step; each wave holds 2 x 4
+// accumulator tiles of 16 x 16 (64 VGPRs); operands go through an LDS image stored [k-pair][row] whose
+// fragment reads and staging writes are bank-conflict-free (kMLD2 below).
 // MFMA operand maps (f64 16x16x4): A lane l = A[l&15][l>>4], B lane l = B[l>>4][l&15],
 // D lane l reg r = D[(l>>4) + 4r][l&15].
 // ------------------------------------------------------------------------------------------------
@@ -239,13 +239,20 @@ __global__ void __launch_bounds__(kWave) row_norm_kernel(const double *__restric
 	}
 }
 
-constexpr int kMU = 128, kMI = 128, kMKC = 32;
+constexpr int kMU = 128, kMI = 128;
 // LDS image of a chunk: [k-pair][row] of double2 {x[row][2p], x[row][2p+1]}, 130 rows per k-pair.
 //   fragment read (ds_read_b64): lanes 0..31 = 16 rows x (k, k+1) of one pair -> 256 contiguous bytes;
-//   staging store (ds_write_b128): an 8-lane group = 2 rows x 4 k-pairs, pair stride 130*16 B = 8 banks mod 32.
-// Both are bank-conflict-free (the first version's [k][row] image conflicted 4-way on the stores).
+//   staging store (ds_write_b128): an 8-lane group = consecutive k-pairs of a row, pair stride 130*16 B = 8 banks
+//   mod 64.  Both are bank-conflict-free (the first version's [k][row] image conflicted 4-way on the stores).
 constexpr int kMLD2 = 130;
 constexpr int kMThreads = 512;
+// dynamic LDS of recommend_mfma_kernel<., KC, ARES> for a given K
+constexpr size_t rec_mfma_lds(int K, int KC, bool ares)
+{
+	const size_t chunk = (size_t) (KC / 2) * kMLD2 * sizeof(double2);
+	const size_t nch = (size_t) ((K + KC - 1) / KC);
+	return (ares ? nch * chunk : 2 * chunk) + 2 * chunk;
+}
 
 struct Top2 {
 	double b1, b2;
@@ -267,11 +274,20 @@ typedef double mf_d4 __attribute__((ext_vector_type(4)));
 
 // 512 threads = 8 waves as 4 (user quarters of 32) x 2 (item halves of 64): two waves per SIMD, so one
 // wave's staging, LDS traffic and arg-max bookkeeping run under the other's matrix instructions.
-template <bool VEC>   // VEC: K even -> rows are 16-B aligned, 16-byte global loads
+//   VEC   K even -> rows are 16-B aligned, 16-byte global loads
+//   KC    k-chunk staged per barrier (a multiple of 4); the host picks one that divides K when it can, so that
+//         no chunk is a short remainder that pays a whole fetch/stage/barrier for a few matrix instructions
+//   ARES  the L block's image (128 users x K) stays resident in LDS for the whole kernel -- it is the same for
+//         every item tile -- and only R chunks are staged (half the global->LDS traffic); needs
+//         ceil(K/KC)*KC/2 + KC pairs of 2080 B to fit the 160 KB of a CU
+template <bool VEC, int KC, bool ARES>
 __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a)
 {
-	__shared__ double2 As[2][kMKC / 2][kMLD2];   // double-buffered: one barrier per chunk
-	__shared__ double2 Bs[2][kMKC / 2][kMLD2];
+	constexpr int PC = KC / 2;                  // k-pairs per chunk
+	constexpr int kChunkD2 = PC * kMLD2;        // double2 elements of one chunk image
+	extern __shared__ double2 rec_lds[];
+	// [ARES: all chunks of A | else: two A buffers][two B buffers]
+	double2 *const Bs0 = rec_lds + (ARES ? ((a.K + KC - 1) / KC) * kChunkD2 : 2 * kChunkD2);
 	__shared__ unsigned long long maskw[kMU][2];
 	__shared__ double red_b1[kMU][2], red_b2[kMU][2];
 	__shared__ int red_i1[kMU][2], red_bad[kMU][2];
@@ -302,38 +318,53 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 		i1[x] = -1;
 	}
 
-	// staging roles: A and B chunks are 128 rows x 32 k; thread -> row tid/4, k-pairs 4m + (tid%4), m = 0..3
-	constexpr int SP = kMKC / 8;
+	// staging roles: a chunk image is 128 rows x PC k-pairs of 16 B; thread -> row tid/4, k-pairs 4m + (tid%4)
+	// (one row pointer per matrix, constant offsets between the pieces; PC=10: the last round is half empty)
+	constexpr int SP = (PC + 3) / 4;
 	const int srow = tid >> 2, sq = tid & 3;
 	const bool a_ok = i0 + srow < a.users;
 	const double *__restrict__ aptr = a.L + (size_t) (a_ok ? i0 + srow : 0) * K;
-	double2 av[SP], bv[SP];
+	double2 av[ARES ? 1 : SP], bv[SP];
 
+	auto load2 = [&](const double *__restrict__ rowp, bool ok, int k) {
+		double2 v = make_double2(0.0, 0.0);
+		if (VEC) {
+			if (ok && k < K) v = *reinterpret_cast<const double2 *>(rowp + k);
+		} else {
+			if (ok && k < K) v.x = rowp[k];
+			if (ok && k + 1 < K) v.y = rowp[k + 1];
+		}
+		return v;
+	};
 	// global -> registers for chunk (tile jt, k offset kc); zero outside the matrices
 	auto fetch = [&](int jt, int kc) {
 		const bool b_ok = jt + srow < a.items;
 		const double *__restrict__ bptr = a.R + (size_t) (b_ok ? jt + srow : 0) * K;
 #pragma unroll
 		for (int m = 0; m < SP; ++m) {
+			if (4 * m + 3 >= PC && 4 * m + sq >= PC) continue;   // only the last round of PC % 4 != 0 can be cut
 			const int k = kc + 8 * m + 2 * sq;
-			if (VEC) {
-				av[m] = (a_ok && k < K) ? *reinterpret_cast<const double2 *>(aptr + k) : make_double2(0.0, 0.0);
-				bv[m] = (b_ok && k < K) ? *reinterpret_cast<const double2 *>(bptr + k) : make_double2(0.0, 0.0);
-			} else {
-				av[m].x = (a_ok && k < K) ? aptr[k] : 0.0;
-				av[m].y = (a_ok && k + 1 < K) ? aptr[k + 1] : 0.0;
-				bv[m].x = (b_ok && k < K) ? bptr[k] : 0.0;
-				bv[m].y = (b_ok && k + 1 < K) ? bptr[k + 1] : 0.0;
-			}
+			if (!ARES) av[m] = load2(aptr, a_ok, k);
+			bv[m] = load2(bptr, b_ok, k);
 		}
 	};
 	auto stage = [&](int buf) {
 #pragma unroll
 		for (int m = 0; m < SP; ++m) {
-			As[buf][4 * m + sq][srow] = av[m];
-			Bs[buf][4 * m + sq][srow] = bv[m];
+			if (4 * m + 3 >= PC && 4 * m + sq >= PC) continue;
+			if (!ARES) rec_lds[buf * kChunkD2 + (4 * m + sq) * kMLD2 + srow] = av[m];
+			Bs0[buf * kChunkD2 + (4 * m + sq) * kMLD2 + srow] = bv[m];
 		}
 	};
+	if (ARES) {
+		// the whole L block once: pairs 0 .. nch*PC-1 (zero beyond K and beyond the last user)
+		const int pairs = ((K + KC - 1) / KC) * PC;
+		for (int sl = tid; sl < kMU * pairs; sl += kMThreads) {
+			const int row = sl / pairs, pr = sl - row * pairs;
+			const bool a_ok = i0 + row < a.users;
+			rec_lds[pr * kMLD2 + row] = load2(a.L + (size_t) (a_ok ? i0 + row : 0) * K, a_ok, 2 * pr);
+		}
+	}
 
 	int buf = 0;
 	fetch(0, 0);
@@ -346,15 +377,15 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 #pragma unroll
 			for (int ti = 0; ti < 4; ++ti) acc[tu][ti] = mf_d4{0.0, 0.0, 0.0, 0.0};
 
-		for (int kc = 0; kc < K; kc += kMKC) {
+		for (int kc = 0; kc < K; kc += KC) {
 			// next chunk (of this tile, or the first of the next tile): global loads fly behind the MFMAs
-			const bool more = kc + kMKC < K || j0 + kMI < a.items;
-			if (kc + kMKC < K)
-				fetch(j0, kc + kMKC);
+			const bool more = kc + KC < K || j0 + kMI < a.items;
+			if (kc + KC < K)
+				fetch(j0, kc + KC);
 			else if (j0 + kMI < a.items)
 				fetch(j0 + kMI, 0);
-			const double *Ab = reinterpret_cast<const double *>(&As[buf][0][0]);
-			const double *Bb = reinterpret_cast<const double *>(&Bs[buf][0][0]);
+			const double *Ab = reinterpret_cast<const double *>(rec_lds + (ARES ? (kc / KC) : buf) * kChunkD2);
+			const double *Bb = reinterpret_cast<const double *>(Bs0 + buf * kChunkD2);
 			auto kstep = [&](int ks) {
 				// k = 4*ks + lq -> pair 2*ks + (lq >> 1), half lq & 1
 				const int po = ((2 * ks + (lq >> 1)) * kMLD2) * 2 + (lq & 1);
@@ -369,9 +400,9 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 					for (int ti = 0; ti < 4; ++ti)
 						acc[tu][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[tu], fb[ti], acc[tu][ti], 0, 0, 0);
 			};
-			if (kc + kMKC <= K) {
+			if (kc + KC <= K) {
 #pragma unroll
-				for (int ks = 0; ks < kMKC / 4; ++ks) kstep(ks);
+				for (int ks = 0; ks < KC / 4; ++ks) kstep(ks);
 			} else {   // last chunk: skip the zero padding beyond K
 				const int ksteps = (K - kc + 3) >> 2;
 				for (int ks = 0; ks < ksteps; ++ks) kstep(ks);
