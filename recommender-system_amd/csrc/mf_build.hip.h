@@ -308,6 +308,13 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 			if (p->max_row_len[kind] < t_eff) continue;
 			std::vector<int> lg, sh;
 			for (int r = 0; r < nrows; ++r) (pt[(size_t) r + 1] - pt[r] >= t_eff ? lg : sh).push_back(r);
+			// longest first: workgroups are dispatched in list order as slots free up, so the long walks start
+			// at once and the short rows fill in behind them (longest-processing-time-first scheduling)
+			auto by_len = [&](int x, int y) { return pt[(size_t) x + 1] - pt[x] > pt[(size_t) y + 1] - pt[y]; };
+			if (!getenv("MF_SWEEP_NOSORT")) {
+				std::stable_sort(sh.begin(), sh.end(), by_len);
+				std::stable_sort(lg.begin(), lg.end(), by_len);
+			}
 			MF_TRY(dev_alloc(&p->long_rows[kind], lg.size()));
 			MF_TRY(dev_alloc(&p->short_rows[kind], sh.size()));
 			MF_TRY_HIP(hipMemcpy(p->long_rows[kind], lg.data(), lg.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -351,10 +358,15 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 			MF_TRY_HIP(raise_lds_limit((const void *) p->sweep.coop, p->lds_bytes_coop));
 		if (p->n_long[0] || p->n_long[1]) {
 			MF_TRY_HIP(raise_lds_limit((const void *) p->sweep.prod, p->lds_bytes));
+			MF_TRY_HIP(raise_lds_limit((const void *) mf::ordered_sum_kernel, (size_t) mf::kRing * 1024));
 			// [16-column slice][entry][16 doubles]; 8 entries of padding per slice: the last block of a row is read whole
 			p->scratch_entries = (size_t) scratch_entries + 8;
 			MF_TRY(dev_alloc(&p->scratch, p->scratch_entries * 16 * (size_t) ((p->K + 15) / 16)));
-			MF_TRY_HIP(hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking));
+			// high priority: the ordered sums are few, latency-bound waves that must get their slots (32 KB of LDS
+			// each) ahead of the thousands of workgroups of the sweep they run under
+			int prio_lo = 0, prio_hi = 0;
+			MF_TRY_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+			MF_TRY_HIP(hipStreamCreateWithPriority(&p->side_stream, hipStreamNonBlocking, prio_hi));
 			MF_TRY_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
 			MF_TRY_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
 		}

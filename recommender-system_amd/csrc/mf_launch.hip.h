@@ -137,12 +137,24 @@ int launch_sweep(mf_plan *p, int kind, int seed)
 		o.X_old = a.X_old;
 		o.X_new = a.X_new;
 		void *oargs[] = {&o};
-		MF_HIP(hipEventRecord(p->ev_fork, p->stream));
-		MF_HIP(hipStreamWaitEvent(p->side_stream, p->ev_fork, 0));
+		// Schedule (MF_SWEEP_SUM_ORDER): "after" (default) -- products kernel and ordered sums on the side stream
+		// while the remaining rows run on the main stream; "under" -- products first on the main stream, then the
+		// ordered sums on the side stream under the sweep of the remaining rows.
+		const char *ord = getenv("MF_SWEEP_SUM_ORDER");
+		const bool under = ord && strcmp(ord, "under") == 0;
+		hipStream_t prod_stream = under ? p->stream : p->side_stream;
+		if (!under) {
+			MF_HIP(hipEventRecord(p->ev_fork, p->stream));
+			MF_HIP(hipStreamWaitEvent(p->side_stream, p->ev_fork, 0));
+		}
 		MF_HIP(hipLaunchKernel((const void *) p->sweep.prod, dim3(b.nrows), dim3(mf::kWave), bargs, p->lds_bytes,
-		                       p->side_stream));
+		                       prod_stream));
+		if (under) {
+			MF_HIP(hipEventRecord(p->ev_fork, p->stream));
+			MF_HIP(hipStreamWaitEvent(p->side_stream, p->ev_fork, 0));
+		}
 		MF_HIP(hipLaunchKernel((const void *) mf::ordered_sum_kernel, dim3(o.nrows * o.nslices), dim3(mf::kWave), oargs,
-		                       0, p->side_stream));
+		                       (size_t) mf::kRing * 1024, p->side_stream));
 		MF_HIP(hipEventRecord(p->ev_join, p->side_stream));
 		a.nrows = p->n_short[kind];
 		a.rowlist = p->short_rows[kind];

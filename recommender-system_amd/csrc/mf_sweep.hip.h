@@ -359,11 +359,11 @@ struct OrderedSumArgs {
 	double *__restrict__ X_new;
 };
 
-constexpr int kRing = 32;   // LDS ring slots of 1 KiB
+constexpr int kRing = 32;   // LDS ring slots of 1 KiB (a power of two; kRing-1 <= 63 = the largest vmcnt)
 
 __global__ void __launch_bounds__(kWave) ordered_sum_kernel(OrderedSumArgs a)
 {
-	__shared__ __attribute__((aligned(1024))) char ring[kRing * 1024];
+	extern __shared__ __attribute__((aligned(1024))) char ring[];   // kRing * 1024 bytes
 	const int lane = threadIdx.x, K = a.K;
 	const unsigned ring_base = (unsigned) (unsigned long long) (__attribute__((address_space(3))) char *) ring;
 	const char *my = ring + 16 * (lane & 7);          // this lane's piece inside an entry
@@ -385,38 +385,61 @@ __global__ void __launch_bounds__(kWave) ordered_sum_kernel(OrderedSumArgs a)
 		asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 		auto issue = [&](int b) {
 			const char *g = src + (size_t) b * 1024;
-			const unsigned m0 = ring_base + (unsigned) (b & (kRing - 1)) * 1024u;
+			const unsigned m0 = __builtin_amdgcn_readfirstlane(ring_base + (unsigned) (b & (kRing - 1)) * 1024u);
 			asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0) : "memory");   // m0 is a reserved register: hipcc re-loads it before each of its own uses
+		};
+		auto read_block = [&](int b, double2 (&v)[8]) {
+			const char *slot = my + (b & (kRing - 1)) * 1024;
+#pragma unroll
+			for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const double2 *>(slot + 128 * e);
+		};
+		auto add_regs = [&](const double2 (&v)[8]) {
+#pragma unroll
+			for (int e = 0; e < 8; ++e) {
+				acc.x = acc.x + v[e].x;
+				acc.y = acc.y + v[e].y;
+			}
 		};
 		auto add_block = [&](int b, int entries) {
 			const char *slot = my + (b & (kRing - 1)) * 1024;
-			if (entries == 8) {
-				double2 v[8];
-#pragma unroll
-				for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const double2 *>(slot + 128 * e);
-#pragma unroll
-				for (int e = 0; e < 8; ++e) {
-					acc.x = acc.x + v[e].x;
-					acc.y = acc.y + v[e].y;
-				}
-			} else {
-				for (int e = 0; e < entries; ++e) {
-					const double2 v = *reinterpret_cast<const double2 *>(slot + 128 * e);
-					acc.x = acc.x + v.x;
-					acc.y = acc.y + v.y;
-				}
+			for (int e = 0; e < entries; ++e) {
+				const double2 v = *reinterpret_cast<const double2 *>(slot + 128 * e);
+				acc.x = acc.x + v.x;
+				acc.y = acc.y + v.y;
 			}
 		};
 		const int ahead = min(nblk, kRing - 1);
 		for (int b = 0; b < ahead; ++b) issue(b);
 		int b = 0;
-		// steady state: kRing-1 blocks are issued beyond b-1, so block b has landed once at most kRing-2 newer DMAs
-		// are outstanding; after adding it, its predecessor's slot is refilled (its LDS reads were consumed by the adds)
-		for (; b + (kRing - 1) < nblk; ++b) {
-			asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
-			add_block(b, 8);
-			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-			issue(b + kRing - 1);
+		// Steady state, software-pipelined by one block: while the dependent adds of block b run (the only true
+		// critical path), the LDS reads of block b+1 are already in flight.  kRing-1 blocks are issued beyond b-1,
+		// so block b+1 has landed once at most kRing-3 newer DMAs are outstanding; the slot refilled after the adds
+		// of block b is that of block b-1, whose values were consumed an iteration ago.
+		if (nblk > kRing - 1) {   // at least one block is still to be issued
+			double2 cur[8], nxt[8];
+			asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRing - 2) : "memory");
+			read_block(0, cur);
+			auto step = [&](int blk, const double2 (&have)[8], double2 (&want)[8]) {
+				asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRing - 3) : "memory");
+				read_block(blk + 1, want);
+				add_regs(have);
+				// no lgkmcnt wait here: the slot refilled now is that of block blk-1, whose ds_reads were issued
+				// two steps ago (LDS serves a wave's instructions in order, and the DMA data arrive ~us later)
+				issue(blk + kRing - 1);
+			};
+			for (; b + kRing < nblk; b += 2) {   // two blocks per trip: the two register sets swap roles, no copies
+				step(b, cur, nxt);
+				step(b + 1, nxt, cur);
+			}
+			if (b + (kRing - 1) < nblk) {
+				step(b, cur, nxt);
+#pragma unroll
+				for (int e = 0; e < 8; ++e) cur[e] = nxt[e];
+				++b;
+			}
+			// `cur` holds block b (a full one: b + kRing - 1 == nblk here), not yet added
+			add_regs(cur);
+			++b;
 		}
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		for (; b < nblk; ++b) add_block(b, min(8, cnt - 8 * b));
