@@ -294,7 +294,8 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 			// memory by raising the threshold (on Netflix-like data most entries sit in long columns)
 			size_t free_b = 0, total_b = 0;
 			(void) hipMemGetInfo(&free_b, &total_b);
-			const size_t cap_entries = std::max<size_t>(free_b / 4 / ((size_t) ((p->K + 15) / 16) * 128), 1);
+			const size_t nsl = (size_t) ((p->K + mf::kSliceCols - 1) / mf::kSliceCols);
+			const size_t cap_entries = std::max<size_t>(free_b / 4 / (nsl * mf::kSliceCols * 8), 1);
 			int t_eff = t_kind;
 			for (;;) {
 				size_t ent = 0;
@@ -359,9 +360,10 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 		if (p->n_long[0] || p->n_long[1]) {
 			MF_TRY_HIP(raise_lds_limit((const void *) p->sweep.prod, p->lds_bytes));
 			MF_TRY_HIP(raise_lds_limit((const void *) mf::ordered_sum_kernel, (size_t) mf::kRing * 1024));
-			// [16-column slice][entry][16 doubles]; 8 entries of padding per slice: the last block of a row is read whole
-			p->scratch_entries = (size_t) scratch_entries + 8;
-			MF_TRY(dev_alloc(&p->scratch, p->scratch_entries * 16 * (size_t) ((p->K + 15) / 16)));
+			// [slice][entry][kSliceCols doubles]; one block of padding per slice: the last block of a row is read whole
+			p->scratch_entries = (size_t) scratch_entries + mf::kBlockEntries;
+			MF_TRY(dev_alloc(&p->scratch, p->scratch_entries * mf::kSliceCols *
+			                                  (size_t) ((p->K + mf::kSliceCols - 1) / mf::kSliceCols)));
 			// high priority: the ordered sums are few, latency-bound waves that must get their slots (32 KB of LDS
 			// each) ahead of the thousands of workgroups of the sweep they run under
 			int prio_lo = 0, prio_hi = 0;

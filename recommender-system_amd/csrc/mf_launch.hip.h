@@ -128,7 +128,7 @@ int launch_sweep(mf_plan *p, int kind, int seed)
 		o.nrows = p->n_long[kind];
 		o.K = p->K;
 		o.seed = seed;
-		o.nslices = (p->K + 15) / 16;
+		o.nslices = (p->K + mf::kSliceCols - 1) / mf::kSliceCols;
 		o.row = p->long_rows[kind];
 		o.sbeg = p->lr_sbeg[kind];
 		o.cnt = p->lr_cnt[kind];

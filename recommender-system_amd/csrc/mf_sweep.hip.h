@@ -164,6 +164,17 @@ struct DmaGeom {
 	static constexpr int kXsBytes = ((KT * 8 + 255) / 256) * 256;
 };
 
+// Extreme-row scratch geometry: the scaled rows are stored [slice of kSliceCols columns][entry][kSliceCols doubles];
+// one ordered-sum wave owns one (row, slice).  Narrower slices = more waves per extreme row, each streaming fewer
+// bytes per entry through its ring of in-flight blocks: the chain of the longest row is bound by what ONE wave can
+// keep in flight, so 8-column slices halve it.
+constexpr int kSliceCols = 8;
+constexpr int kSlicePieces = kSliceCols / 2;          // 16-B pieces per (slice, entry)
+constexpr int kBlockEntries = kWave / kSlicePieces;   // entries per 1-KiB DMA block
+constexpr int kSliceShift = kSliceCols == 8 ? 3 : 4;  // log2(kSliceCols)
+constexpr int kPieceShift = kSliceShift - 1;
+static_assert(kSliceCols == 8 || kSliceCols == 16, "slice width");
+
 // KT > 0: K is a compile-time constant (phase A fully unrolled).  KT == 0: any even K up to 128*NPASS at run
 // time (phase A unrolled by four) -- same data movement, so an unusual K does not fall back to the
 // register-staged kernel.
@@ -272,21 +283,22 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 				e = a.c2 * (my_val - dot);
 			}
 			if (PRODUCTS) {
-				// scratch layout: [k-slice of 16 columns][entry][16 doubles] -- every (slice, entry) is one aligned
-				// 128-B line and a slice is contiguous over the entries, so ordered_sum_kernel streams it linearly
+				// scratch layout: [k-slice][entry][kSliceCols doubles] -- a slice is contiguous over the entries, so
+				// ordered_sum_kernel streams it linearly
 				const char *tb = tile + voff;
 				const size_t pos = (size_t) (a.seg_out[it] + (c - beg));
 				for (int n = 0; n < cnt; ++n) {
 					const double en = readlane_f64(e, n);
 #pragma unroll
 					for (int p = 0; p < NP; ++p) {
-						const int q = lane + kWave * p;   // 16-B piece: slice q / 8, position q % 8 in its line
+						const int q = lane + kWave * p;   // 16-B piece: slice q / kSlicePieces, position q % kSlicePieces
 						if (q < P) {
 							double2 t = *reinterpret_cast<const double2 *>(tb + n * S + 1024 * p);
 							t.x = en * t.x;
 							t.y = en * t.y;
-							*reinterpret_cast<double2 *>(a.scratch + (((size_t) (q >> 3) * a.scratch_entries + pos + n) << 4) +
-							                             2 * (q & 7)) = t;
+							*reinterpret_cast<double2 *>(a.scratch +
+							                             (((size_t) (q >> kPieceShift) * a.scratch_entries + pos + n) << kSliceShift) +
+							                             2 * (q & (kSlicePieces - 1))) = t;
 						}
 					}
 				}
@@ -366,20 +378,21 @@ __global__ void __launch_bounds__(kWave) ordered_sum_kernel(OrderedSumArgs a)
 	extern __shared__ __attribute__((aligned(1024))) char ring[];   // kRing * 1024 bytes
 	const int lane = threadIdx.x, K = a.K;
 	const unsigned ring_base = (unsigned) (unsigned long long) (__attribute__((address_space(3))) char *) ring;
-	const char *my = ring + 16 * (lane & 7);          // this lane's piece inside an entry
+	const char *my = ring + 16 * (lane & (kSlicePieces - 1));   // this lane's piece inside an entry
 	const int total = a.nrows * a.nslices;
 	for (int it = blockIdx.x; it < total; it += gridDim.x) {
 		const int li = it / a.nslices, slice = it % a.nslices;
 		const int r = a.row[li], cnt = a.cnt[li];
-		const int k0 = slice * 16 + 2 * (lane & 7);       // this lane's two columns (all 8 lane groups agree)
+		const int k0 = slice * kSliceCols + 2 * (lane & (kSlicePieces - 1));   // this lane's two columns (all lane groups agree)
 		const bool live = k0 < K;                         // K is even: k0 + 1 < K too
 		double2 acc = (a.seed && live) ? *reinterpret_cast<const double2 *>(a.X_old + (size_t) r * K + k0)
 		                               : make_double2(0.0, 0.0);
-		// block b of the row in this slice: 8 entries = 1 KiB at ((slice * entries + sbeg + 8b) * 128) bytes
+		// block b of the row in this slice: kBlockEntries entries = 1 KiB, lane-linear
 		const char *src = reinterpret_cast<const char *>(
-		                      a.scratch + (((size_t) slice * a.scratch_entries + (size_t) a.sbeg[li]) << 4)) +
+		                      a.scratch + (((size_t) slice * a.scratch_entries + (size_t) a.sbeg[li]) << kSliceShift)) +
 		                  16 * lane;
-		const int nblk = (cnt + 7) >> 3;
+		constexpr int EB = kBlockEntries, EBYTES = kSliceCols * 8;
+		const int nblk = (cnt + EB - 1) / EB;
 
 		// every ordinary load above must have landed before the hand-counted region starts
 		asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -388,14 +401,14 @@ __global__ void __launch_bounds__(kWave) ordered_sum_kernel(OrderedSumArgs a)
 			const unsigned m0 = __builtin_amdgcn_readfirstlane(ring_base + (unsigned) (b & (kRing - 1)) * 1024u);
 			asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0) : "memory");   // m0 is a reserved register: hipcc re-loads it before each of its own uses
 		};
-		auto read_block = [&](int b, double2 (&v)[8]) {
+		auto read_block = [&](int b, double2 (&v)[EB]) {
 			const char *slot = my + (b & (kRing - 1)) * 1024;
 #pragma unroll
-			for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const double2 *>(slot + 128 * e);
+			for (int e = 0; e < EB; ++e) v[e] = *reinterpret_cast<const double2 *>(slot + EBYTES * e);
 		};
-		auto add_regs = [&](const double2 (&v)[8]) {
+		auto add_regs = [&](const double2 (&v)[EB]) {
 #pragma unroll
-			for (int e = 0; e < 8; ++e) {
+			for (int e = 0; e < EB; ++e) {
 				acc.x = acc.x + v[e].x;
 				acc.y = acc.y + v[e].y;
 			}
@@ -403,7 +416,7 @@ __global__ void __launch_bounds__(kWave) ordered_sum_kernel(OrderedSumArgs a)
 		auto add_block = [&](int b, int entries) {
 			const char *slot = my + (b & (kRing - 1)) * 1024;
 			for (int e = 0; e < entries; ++e) {
-				const double2 v = *reinterpret_cast<const double2 *>(slot + 128 * e);
+				const double2 v = *reinterpret_cast<const double2 *>(slot + EBYTES * e);
 				acc.x = acc.x + v.x;
 				acc.y = acc.y + v.y;
 			}
@@ -416,10 +429,10 @@ __global__ void __launch_bounds__(kWave) ordered_sum_kernel(OrderedSumArgs a)
 		// so block b+1 has landed once at most kRing-3 newer DMAs are outstanding; the slot refilled after the adds
 		// of block b is that of block b-1, whose values were consumed an iteration ago.
 		if (nblk > kRing - 1) {   // at least one block is still to be issued
-			double2 cur[8], nxt[8];
+			double2 cur[EB], nxt[EB];
 			asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRing - 2) : "memory");
 			read_block(0, cur);
-			auto step = [&](int blk, const double2 (&have)[8], double2 (&want)[8]) {
+			auto step = [&](int blk, const double2 (&have)[EB], double2 (&want)[EB]) {
 				asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRing - 3) : "memory");
 				read_block(blk + 1, want);
 				add_regs(have);
@@ -434,7 +447,7 @@ __global__ void __launch_bounds__(kWave) ordered_sum_kernel(OrderedSumArgs a)
 			if (b + (kRing - 1) < nblk) {
 				step(b, cur, nxt);
 #pragma unroll
-				for (int e = 0; e < 8; ++e) cur[e] = nxt[e];
+				for (int e = 0; e < EB; ++e) cur[e] = nxt[e];
 				++b;
 			}
 			// `cur` holds block b (a full one: b + kRing - 1 == nblk here), not yet added
@@ -442,9 +455,9 @@ __global__ void __launch_bounds__(kWave) ordered_sum_kernel(OrderedSumArgs a)
 			++b;
 		}
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		for (; b < nblk; ++b) add_block(b, min(8, cnt - 8 * b));
+		for (; b < nblk; ++b) add_block(b, min(EB, cnt - EB * b));
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the ring is reused by the next (row, slice)
-		if (live && lane < 8) *reinterpret_cast<double2 *>(a.X_new + (size_t) r * K + k0) = acc;
+		if (live && lane < kSlicePieces) *reinterpret_cast<double2 *>(a.X_new + (size_t) r * K + k0) = acc;
 	}
 }
 
