@@ -253,10 +253,17 @@ int mf_plan_flip(mf_plan *p)
 static int iterate_eager(mf_plan *p, int iters)
 {
 	for (int it = 0; it < iters; ++it) {
-		int rc = launch_sweep(p, 0, 1);
+		// Both sweeps read only the frozen generation (matFact.c:38-39), so the ordered sums of the item sweep's
+		// extreme rows may run on the side stream UNDER the whole user sweep; they are joined before the flip.
+		// Not when the user sweep has extreme rows of its own: it would reuse the scratch buffer.
+		int rc = launch_sweep(p, 0, 1, /*defer_join=*/p->n_long[1] == 0 && !getenv("MF_SWEEP_NO_DEFER"));
 		if (rc != MF_OK) return rc;
 		rc = launch_sweep(p, 1, 1);
 		if (rc != MF_OK) return rc;
+		if (p->join_pending) {
+			MF_HIP(hipStreamWaitEvent(p->stream, p->ev_join, 0));
+			p->join_pending = false;
+		}
 		p->cur ^= 1;
 	}
 	return MF_OK;

@@ -63,7 +63,9 @@ int choose_sweep(mf_plan *p)
 }
 
 
-int launch_sweep(mf_plan *p, int kind, int seed)
+// defer_join: leave the ordered sums of the extreme rows running on the side stream when the call returns
+// (p->join_pending); the caller joins before anything reads the new generation.
+int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 {
 	mf::SweepArgs a;
 	a.K = p->K;
@@ -162,7 +164,10 @@ int launch_sweep(mf_plan *p, int kind, int seed)
 		if (a.nrows > 0)
 			MF_HIP(hipLaunchKernel((const void *) p->sweep.fn, dim3(std::min(a.nrows, 1 << 20)), dim3(mf::kWave), args,
 			                       p->lds_bytes, p->stream));
-		MF_HIP(hipStreamWaitEvent(p->stream, p->ev_join, 0));
+		if (defer_join)
+			p->join_pending = true;
+		else
+			MF_HIP(hipStreamWaitEvent(p->stream, p->ev_join, 0));
 	} else {
 		MF_HIP(hipLaunchKernel((const void *) fn, dim3(grid), dim3(block), args, lds, p->stream));
 	}

@@ -59,9 +59,7 @@ class ShardedFactorization:
     def _step(self):
         p = self.plan
         if self.world == 1 and not self.force_collective:
-            p.sweep_items(True)
-            p.sweep_users()
-            p.flip()
+            p.iterate(1)      # the library's own iteration (item sweep, user sweep, flip): what the CLI calls
             return
         p.sweep_items(self.rank == 0)
         nxt = self._next_tensor()
