@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 	extern __shared__ double2 rec_lds[];
 	// [ARES: all chunks of A | else: two A buffers][two B buffers]
 	double2 *const Bs0 = rec_lds + (ARES ? ((a.K + KC - 1) / KC) * kChunkD2 : 2 * kChunkD2);
-	__shared__ unsigned long long maskw[kMU][2];
+	__shared__ unsigned long long maskw[2][kMU][2];   // [tile parity][user][item half]
 	__shared__ double red_b1[kMU][2], red_b2[kMU][2];
 	__shared__ int red_i1[kMU][2], red_bad[kMU][2];
 
@@ -299,12 +299,15 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 	const int K = a.K;
 	const double ninf = -__builtin_inf();
 
-	// mask walker: threads 0..127, one user each
-	int cur = 0, cend = 0, nextcol = INT32_MAX;
+	// mask walker: threads 0..127, one user each.  The next TWO rated items are held in registers: consuming one
+	// only issues the load of the one after the next, so the walk does not wait on memory (it used to stall the
+	// two walker waves -- and with them the whole workgroup at the next barrier -- for a load latency per tile).
+	int cur = 0, cend = 0, nextcol = INT32_MAX, nextcol2 = INT32_MAX;
 	if (tid < kMU && i0 + tid < a.users) {
 		cur = a.csr_ptr[i0 + tid];
 		cend = a.csr_ptr[i0 + tid + 1];
 		nextcol = cur < cend ? a.csr_idx[cur] : INT32_MAX;
+		nextcol2 = cur + 1 < cend ? a.csr_idx[cur + 1] : INT32_MAX;
 	}
 
 	// running top-2 of the 8 rows this lane sees: row(tu, r) = 32*wr + 16*tu + lq + 4*r
@@ -377,6 +380,33 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 #pragma unroll
 			for (int ti = 0; ti < 4; ++ti) acc[tu][ti] = mf_d4{0.0, 0.0, 0.0, 0.0};
 
+		// rated-item mask of this tile: bit jj of word w = item j0 + 64*w + jj is rated or beyond the last item.
+		// Written at the START of the tile into the parity's copy: the chunk barriers below publish it before the
+		// arg-max step reads it, and the other parity is not rewritten before every wave has passed them again.
+		const int par = (j0 / kMI) & 1;
+		if (tid < kMU) {
+			unsigned long long m0 = 0, m1 = 0;
+			while (nextcol < j0 + kMI) {
+				const int o = nextcol - j0;
+				if (o >= 64)
+					m1 |= 1ull << (o - 64);
+				else if (o >= 0)
+					m0 |= 1ull << o;
+				++cur;
+				nextcol = nextcol2;
+				nextcol2 = cur + 1 < cend ? a.csr_idx[cur + 1] : INT32_MAX;
+			}
+			const int left = a.items - j0;   // > 0
+			if (left < 64) {
+				m0 |= ~0ull << left;
+				m1 = ~0ull;
+			} else if (left < 128) {
+				m1 |= ~0ull << (left - 64);
+			}
+			maskw[par][tid][0] = m0;
+			maskw[par][tid][1] = m1;
+		}
+
 		for (int kc = 0; kc < K; kc += KC) {
 			// next chunk (of this tile, or the first of the next tile): global loads fly behind the MFMAs
 			const bool more = kc + KC < K || j0 + kMI < a.items;
@@ -413,35 +443,12 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 			buf ^= 1;
 		}
 
-		// rated-item mask of this tile: bit jj of word w = item j0 + 64*w + jj is rated or beyond the last item
-		if (tid < kMU) {
-			unsigned long long m0 = 0, m1 = 0;
-			while (nextcol < j0 + kMI) {
-				const int o = nextcol - j0;
-				if (o >= 64)
-					m1 |= 1ull << (o - 64);
-				else if (o >= 0)
-					m0 |= 1ull << o;
-				++cur;
-				nextcol = cur < cend ? a.csr_idx[cur] : INT32_MAX;
-			}
-			const int left = a.items - j0;   // > 0
-			if (left < 64) {
-				m0 |= ~0ull << left;
-				m1 = ~0ull;
-			} else if (left < 128) {
-				m1 |= ~0ull << (left - 64);
-			}
-			maskw[tid][0] = m0;
-			maskw[tid][1] = m1;
-		}
-		__syncthreads();
 #pragma unroll
 		for (int tu = 0; tu < 2; ++tu)
 #pragma unroll
 			for (int r = 0; r < 4; ++r) {
 				const int x = tu * 4 + r;
-				const unsigned long long m = maskw[32 * wr + 16 * tu + lq + 4 * r][wc] >> lr;
+				const unsigned long long m = maskw[par][32 * wr + 16 * tu + lq + 4 * r][wc] >> lr;
 				// cheap reject: after the first tiles almost no score beats the row's runner-up
 				bool any = false;
 #pragma unroll
@@ -467,7 +474,6 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 					}
 				}
 			}
-		__syncthreads();   // maskw is rewritten by the next tile
 	}
 
 	// merge the 16 lanes (lr) that share a row, then the two item halves (wc), then decide
