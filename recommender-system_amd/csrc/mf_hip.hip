@@ -355,26 +355,43 @@ int mf_plan_recommend(mf_plan *p, int32_t *best)
 		m.best = p->best_dev;
 		m.ulist = p->ulist;
 		m.ucount = p->ucount;
-		// Form: the L block resident in LDS (it is the same for every item tile; only R chunks are staged) whenever
-		// its image fits beside the two R buffers -- K <= 64 with 32-deep chunks, K = 80 / 100 with 20-deep chunks
-		// (5 x 20 at K=100 instead of 32+32+32+4: no short remainder chunk) -- else both operands staged per chunk.
-		// Measured on 1e6 x 1e5: K=100 48.8 vs 47.7 TFLOP/s, K=64 49.9 vs 46.8, K=30 37.5 vs 34.1.
+		// Form.  The L block's image stays resident in LDS (it is the same for every item tile) whenever it fits
+		// beside the two R buffers, and the R chunks then go global -> LDS by LDS-DMA (even K): K <= 64 with 32-deep
+		// chunks, up to K = 100 with 24- or 20-deep ones -- the depth with the fewest chunks wins, an exact divisor
+		// of K on ties (K=100: 5 x 20 instead of 32+32+32+4).  Larger K: both operands staged through registers.
+		// Measured on 1e6 x 1e5 (profiles/r01/recommend_resident_L_ab.txt): K=100 55.4 vs 48.9 TFLOP/s, K=64 54.3
+		// vs 50.2, K=30 41.1 vs 37.7.
 		typedef void (*RecFn)(mf::RecMfmaArgs);
 		const bool vec = (p->K & 1) == 0;
 		const char *ares_env = getenv("MF_RECOMMEND_ARES");   // "0" disables the resident-L form (tests, A/B)
+		const char *bdma_env = getenv("MF_RECOMMEND_BDMA");   // "0": stage R chunks through registers (A/B)
 		const bool allow = !(ares_env && ares_env[0] == '0');
+		const bool allow_dma = vec && !(bdma_env && bdma_env[0] == '0');
 		const size_t static_lds = 8 * 1024, cu_lds = 160 * 1024;   // masks + merge arrays, rounded up
 		int kc = 32;
 		bool ares = false;
-		if (allow && mf::rec_mfma_lds(p->K, 32, true) + static_lds <= cu_lds) {
-			ares = true;
-		} else if (allow && p->K % 20 == 0 && mf::rec_mfma_lds(p->K, 20, true) + static_lds <= cu_lds) {
-			ares = true;
-			kc = 20;
+		if (allow) {
+			int best_nch = 1 << 30;
+			for (int cand : {32, 24, 20}) {
+				if (cand == 24 && !allow_dma) continue;                    // 24 exists in the DMA form only
+				if (cand == 20 && p->K % 20 != 0 && !allow_dma) continue;   // register form: exact multiples only
+				if (mf::rec_mfma_lds(p->K, cand, true) + static_lds > cu_lds) continue;
+				const int nch = (p->K + cand - 1) / cand;
+				if (nch < best_nch || (nch == best_nch && p->K % cand == 0 && p->K % kc != 0)) {
+					best_nch = nch;
+					kc = cand;
+					ares = true;
+				}
+			}
 		}
+		const bool bdma = ares && allow_dma;
 		RecFn fn;
-		if (kc == 20)
-			fn = mf::recommend_mfma_kernel<true, 20, true>;   // K % 20 == 0 is even
+		if (kc == 24)
+			fn = mf::recommend_mfma_kernel<true, 24, true, true>;
+		else if (kc == 20)   // even K here
+			fn = bdma ? mf::recommend_mfma_kernel<true, 20, true, true> : mf::recommend_mfma_kernel<true, 20, true, false>;
+		else if (bdma)
+			fn = mf::recommend_mfma_kernel<true, 32, true, true>;
 		else
 			fn = ares ? (vec ? mf::recommend_mfma_kernel<true, 32, true> : mf::recommend_mfma_kernel<false, 32, true>)
 			          : (vec ? mf::recommend_mfma_kernel<true, 32, false> : mf::recommend_mfma_kernel<false, 32, false>);

@@ -280,9 +280,16 @@ typedef double mf_d4 __attribute__((ext_vector_type(4)));
 //   ARES  the L block's image (128 users x K) stays resident in LDS for the whole kernel -- it is the same for
 //         every item tile -- and only R chunks are staged (half the global->LDS traffic); needs
 //         ceil(K/KC)*KC/2 + KC pairs of 2080 B to fit the 160 KB of a CU
-template <bool VEC, int KC, bool ARES>
+//   BDMA  (needs VEC and ARES) R chunks go global -> LDS by LDS-DMA instead of through registers: one
+//         instruction fills 64 rows of one k-pair of the image (lane = row, 16 B each); no staging registers,
+//         no ds_write, no address arithmetic per piece.  Inline asm with a hand-placed s_waitcnt vmcnt(0) in
+//         front of the chunk barrier: the builtin would make hipcc wait for the DMA before every fragment read.
+template <bool VEC, int KC, bool ARES, bool BDMA = false>
 __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a)
 {
+	static_assert(!BDMA || (VEC && ARES), "LDS-DMA staging needs 16-B aligned rows and a resident L image");
+	// (DMA staging of BOTH operands for larger K was measured slower than register staging: K=128 51.5 vs 53.5,
+	// K=256 52.8 vs 55.1 TFLOP/s -- not instantiated.)
 	constexpr int PC = KC / 2;                  // k-pairs per chunk
 	constexpr int kChunkD2 = PC * kMLD2;        // double2 elements of one chunk image
 	extern __shared__ double2 rec_lds[];
@@ -359,6 +366,28 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 			Bs0[buf * kChunkD2 + (4 * m + sq) * kMLD2 + srow] = bv[m];
 		}
 	};
+	// LDS-DMA staging of an R chunk: instruction t (t = wave, wave + 8, ...) covers k-pair t/2, rows 64*(t%2)..+63
+	const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+	const unsigned bs_lds = (unsigned) (unsigned long long) (__attribute__((address_space(3))) char *) Bs0;
+	auto dma_image = [&](const double *__restrict__ X, int first_row, int last_row, unsigned lds_base, int kc, int buf) {
+#pragma unroll
+		for (int t0 = 0; t0 < 2 * PC; t0 += 8) {
+			const int t = t0 + wave_u;
+			const int pr = t >> 1, rb = (t & 1) * 64, k = kc + 2 * pr;
+			if (t < 2 * PC && k < K) {   // wave-uniform
+				const int row = min(first_row + rb + lane, last_row);   // rows beyond the matrix are masked / never stored
+				const char *g = reinterpret_cast<const char *>(X + (size_t) row * K + k);
+				const unsigned m0 = __builtin_amdgcn_readfirstlane(lds_base + (unsigned) ((buf * kChunkD2 + pr * kMLD2 + rb) * 16));
+				asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0) : "memory");
+			}
+		}
+	};
+	auto dma_chunk = [&](int jt, int kc, int buf) { dma_image(a.R, jt, a.items - 1, bs_lds, kc, buf); };
+	if (BDMA) {
+		// pairs beyond K are never written: zero the staged buffers once so that they hold no NaN patterns
+		for (int sl = tid; sl < 2 * kChunkD2; sl += kMThreads) Bs0[sl] = make_double2(0.0, 0.0);
+		__syncthreads();
+	}
 	if (ARES) {
 		// the whole L block once: pairs 0 .. nch*PC-1 (zero beyond K and beyond the last user)
 		const int pairs = ((K + KC - 1) / KC) * PC;
@@ -370,8 +399,13 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 	}
 
 	int buf = 0;
-	fetch(0, 0);
-	stage(0);
+	if (BDMA) {
+		dma_chunk(0, 0, 0);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	} else {
+		fetch(0, 0);
+		stage(0);
+	}
 	__syncthreads();
 	for (int j0 = 0; j0 < a.items; j0 += kMI) {
 		mf_d4 acc[2][4];
@@ -410,7 +444,12 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 		for (int kc = 0; kc < K; kc += KC) {
 			// next chunk (of this tile, or the first of the next tile): global loads fly behind the MFMAs
 			const bool more = kc + KC < K || j0 + kMI < a.items;
-			if (kc + KC < K)
+			if (BDMA) {   // straight into the OTHER buffer (last read one chunk ago; every wave passed a barrier since)
+				if (kc + KC < K)
+					dma_chunk(j0, kc + KC, buf ^ 1);
+				else if (j0 + kMI < a.items)
+					dma_chunk(j0 + kMI, 0, buf ^ 1);
+			} else if (kc + KC < K)
 				fetch(j0, kc + KC);
 			else if (j0 + kMI < a.items)
 				fetch(j0 + kMI, 0);
@@ -438,7 +477,10 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 				for (int ks = 0; ks < ksteps; ++ks) kstep(ks);
 			}
 			// registers -> the OTHER buffer (last read one chunk ago; every wave passed a barrier since)
-			if (more) stage(buf ^ 1);
+			if (BDMA)
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			else if (more)
+				stage(buf ^ 1);
 			__syncthreads();
 			buf ^= 1;
 		}

@@ -287,6 +287,26 @@ def test_recommend_forms_agree_with_oracle(capi, orc, impl, monkeypatch):
         assert info == -1 if impl == "exact" else info >= 0
 
 
+@pytest.mark.parametrize("k", [20, 48, 64, 66, 70, 72, 80, 90, 96, 98, 100, 104, 128])
+def test_recommend_every_chunk_depth_and_staging_form(capi, orc, k, monkeypatch):
+    """The MFMA pass picks its chunk depth (32 / 24 / 20), resident-L image and LDS-DMA staging from K: every
+    combination, with partial last chunks (66, 70, 90, 98), against the oracle -- with and without the DMA form."""
+    u, i = 300, 517
+    rng = np.random.default_rng(100 + k)
+    L = rng.standard_normal((u, k))
+    R = rng.standard_normal((i, k))
+    R[i - 1] = R[0]
+    d = random_instance(200 + k, u, i, k, density=0.2, full_rows=(7,))
+    want = orc.recommend(orc.Instance(**d), L, R)
+    for bdma in ("1", "0"):
+        monkeypatch.setenv("MF_RECOMMEND_BDMA", bdma)
+        plan = capi.Plan(u, i, k, 0.0, d["row"], d["col"], d["val"])
+        plan.upload(L, R)
+        best = plan.recommend()
+        plan.close()
+        assert np.array_equal(best, want), (k, bdma)
+
+
 def test_mfma_certification_sends_near_ties_to_the_exact_pass(capi, orc):
     """Scores closer than the rounding bound must not be decided by the matrix cores."""
     u, i, k = 200, 300, 64
