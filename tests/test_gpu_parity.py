@@ -673,3 +673,29 @@ def test_four_ranks_one_gpu_grid_bench(capi):
     # the grid's factors differ from the single-shard ones in the last bits (re-associated sums): identical
     # top-1 lists unless a user has two items within that noise, which this instance should not have
     assert out["check"]["recommend_differs"] <= 1, out["check"]
+
+
+def test_power_law_extreme_path_equals_plain_path_at_scale(capi, monkeypatch):
+    """A tenth of the Netflix-shaped instance of bench.py (48k x 4.4k, ~7e6 entries, top item rated by nearly every
+    user): the extreme-row path (products, ordered sums under the user sweep, join before the flip) must give the
+    bits of the plain one-wave-per-row path, which the smaller tests pin on the oracle."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    cfg = bench.CONFIGS["nflx"]
+    U, I, K = cfg["users"] // 10, cfg["items"] // 4, 30
+    row, col, val = bench.power_law_large(cfg["seed"], U, I, cfg["power_law_nnz"] // 10)
+    L0, R0 = capi.init_factors(U, I, K)
+    got = {}
+    for mode in ("split", "plain"):
+        if mode == "plain":
+            monkeypatch.setenv("MF_SWEEP_SKEW", "0")
+        plan = capi.Plan(U, I, K, 1e-6, row, col, val)
+        desc = plan.describe()
+        plan.upload(L0, R0)
+        plan.iterate(3)
+        got[mode] = plan.download()
+        plan.close()
+        assert ("long_rows=0/0" in desc) == (mode == "plain"), desc
+    assert np.array_equal(got["split"][0], got["plain"][0]) and np.array_equal(got["split"][1], got["plain"][1])
