@@ -109,7 +109,21 @@ struct DevTmp {   // frees its buffers on scope exit
 };
 
 // Builds csr_* and csc_* of plan p from host SoA entries.  Returns MF_ERR_ARGUMENT for out-of-range indices.
-int build_on_device(mf_plan *p, const mf_shard *s, std::vector<int> &csr_ptr_host, std::vector<int> &csc_ptr_host)
+// the reference's array of structs -> the three arrays the build works on
+__global__ void __launch_bounds__(256) split_entries_kernel(const mf_entry *__restrict__ e, int64_t nnz,
+                                                            int *__restrict__ row, int *__restrict__ col,
+                                                            double *__restrict__ val)
+{
+	const int64_t n = (int64_t) blockIdx.x * 256 + threadIdx.x;
+	if (n >= nnz) return;
+	const mf_entry x = e[n];
+	row[n] = x.row;
+	col[n] = x.col;
+	val[n] = x.value;
+}
+
+int build_on_device(mf_plan *p, const mf_shard *s, const mf_entry *aos, std::vector<int> &csr_ptr_host,
+                    std::vector<int> &csc_ptr_host)
 {
 	const int64_t nnz = s->nnz;
 	const size_t nz = (size_t) nnz;
@@ -140,11 +154,19 @@ int build_on_device(mf_plan *p, const mf_shard *s, std::vector<int> &csr_ptr_hos
 	// the values land directly in csr_val when the input is row-sorted (the usual case); otherwise csc_val is
 	// used as the staging copy of the file-order values and overwritten last
 	double *d_val = p->csc_val;
-	MF_HIP(hipMemcpyAsync(d_row, s->row, nz * sizeof(int), hipMemcpyHostToDevice, st));
-	MF_HIP(hipMemcpyAsync(d_col, s->col, nz * sizeof(int), hipMemcpyHostToDevice, st));
-	MF_HIP(hipMemcpyAsync(p->csr_val, s->val, nz * sizeof(double), hipMemcpyHostToDevice, st));
-	MF_HIP(hipMemsetAsync(d_flags, 0, 2 * sizeof(int), st));
 	const unsigned grid = (unsigned) ((nnz + 255) / 256);
+	if (aos) {
+		// one upload of the 16-byte structs, split on the device (no host pass over the entries)
+		mf_entry *d_aos = nullptr;
+		if ((rc = tmp.get(&d_aos, nz)) != MF_OK) return rc;
+		MF_HIP(hipMemcpyAsync(d_aos, aos, nz * sizeof(mf_entry), hipMemcpyHostToDevice, st));
+		hipLaunchKernelGGL(split_entries_kernel, dim3(grid), dim3(256), 0, st, d_aos, nnz, d_row, d_col, p->csr_val);
+	} else {
+		MF_HIP(hipMemcpyAsync(d_row, s->row, nz * sizeof(int), hipMemcpyHostToDevice, st));
+		MF_HIP(hipMemcpyAsync(d_col, s->col, nz * sizeof(int), hipMemcpyHostToDevice, st));
+		MF_HIP(hipMemcpyAsync(p->csr_val, s->val, nz * sizeof(double), hipMemcpyHostToDevice, st));
+	}
+	MF_HIP(hipMemsetAsync(d_flags, 0, 2 * sizeof(int), st));
 	hipLaunchKernelGGL(prep_keys_kernel, dim3(grid), dim3(256), 0, st, d_row, d_col, nnz, p->u0, p->uc, p->items,
 	                   key_in, perm_in, d_flags);
 	int flags[2] = {0, 0};
@@ -205,10 +227,32 @@ int build_on_device(mf_plan *p, const mf_shard *s, std::vector<int> &csr_ptr_hos
 
 // CSR over the shard's users and CSC over the items, on the device (default) or bucketed on the host
 // (MF_BUILD=host, kept for A/B tests); rptr / cptr return the two row-pointer arrays for the schedule decisions.
-int build_sparse(mf_plan *p, const mf_shard *s, std::vector<int> &rptr, std::vector<int> &cptr)
+int build_sparse(mf_plan *p, const mf_shard *s_in, const mf_entry *aos, std::vector<int> &rptr, std::vector<int> &cptr)
 {
 	const char *where = getenv("MF_BUILD");
 	if (where && strcmp(where, "host") == 0) {
+		// host fallback of the BUILD only (tests): works on the three arrays
+		mf_shard sh = *s_in;
+		std::vector<int32_t> hrow, hcol;
+		std::vector<double> hval;
+		if (aos) {
+			try {
+				hrow.resize((size_t) sh.nnz);
+				hcol.resize((size_t) sh.nnz);
+				hval.resize((size_t) sh.nnz);
+			} catch (const std::bad_alloc &) {
+				return MF_ERR_NO_MEMORY;
+			}
+			for (int64_t n = 0; n < sh.nnz; ++n) {
+				hrow[(size_t) n] = aos[n].row;
+				hcol[(size_t) n] = aos[n].col;
+				hval[(size_t) n] = aos[n].value;
+			}
+			sh.row = hrow.data();
+			sh.col = hcol.data();
+			sh.val = hval.data();
+		}
+		const mf_shard *s = &sh;
 		for (int64_t n = 0; n < s->nnz; ++n)
 			if (s->row[n] < s->user_begin || s->row[n] >= s->user_begin + s->user_count || s->col[n] < 0 ||
 			    s->col[n] >= s->items)
@@ -243,7 +287,7 @@ int build_sparse(mf_plan *p, const mf_shard *s, std::vector<int> &rptr, std::vec
 			MF_TRY_HIP(hipMemcpy(p->csc_val, val.data(), nz * sizeof(double), hipMemcpyHostToDevice));
 		}
 	} else {
-		MF_TRY(build_on_device(p, s, rptr, cptr));
+		MF_TRY(build_on_device(p, s_in, aos, rptr, cptr));
 	}
 	return MF_OK;
 }

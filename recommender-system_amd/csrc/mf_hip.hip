@@ -52,13 +52,17 @@ int mf_backend_device_count(void)
 	return n;
 }
 
-int mf_plan_create(mf_plan **out, const mf_shard *s)
+}   // extern "C"
+
+// `aos` (optional): the entries as the reference's array of (row, col, value) structs; they are then uploaded as they
+// are and split into the three arrays on the device (the level-1 entry points: no host-side copy of 1e8 entries).
+static int plan_create_impl(mf_plan **out, const mf_shard *s, const mf_entry *aos)
 {
 	if (!out) return MF_ERR_ARGUMENT;
 	*out = nullptr;
 	if (!s || s->users_total < 0 || s->items < 0 || s->features < 1 || s->nnz < 0 || s->user_begin < 0 ||
 	    s->user_count < 0 || (int64_t) s->user_begin + s->user_count > s->users_total ||
-	    s->nnz > INT32_MAX - 64 || (s->nnz > 0 && (!s->row || !s->col || !s->val)))
+	    s->nnz > INT32_MAX - 64 || (s->nnz > 0 && !aos && (!s->row || !s->col || !s->val)))
 		return MF_ERR_ARGUMENT;
 	// caller-owned R buffers: both or neither, and 16-B aligned (the gather moves 16-byte pieces of rows)
 	if ((s->items_ext[0] == nullptr) != (s->items_ext[1] == nullptr) || ((uintptr_t) s->items_ext[0] & 15) ||
@@ -108,7 +112,7 @@ int mf_plan_create(mf_plan **out, const mf_shard *s)
 	} while (0)
 	{
 		std::vector<int> rptr, cptr;
-		MF_TRY(build_sparse(p, s, rptr, cptr));
+		MF_TRY(build_sparse(p, s, aos, rptr, cptr));
 		MF_TRY(plan_row_schedule(p, rptr, cptr));
 	}
 
@@ -139,6 +143,10 @@ int mf_plan_create(mf_plan **out, const mf_shard *s)
 	*out = p;
 	return MF_OK;
 }
+
+extern "C" {
+
+int mf_plan_create(mf_plan **out, const mf_shard *s) { return plan_create_impl(out, s, nullptr); }
 
 void mf_plan_destroy(mf_plan *p)
 {
@@ -522,24 +530,11 @@ int mf_plan_describe(mf_plan *p, char *buf, int buflen)
 
 /* ---------------------------------------------------------------------------------------- LEVEL 1 */
 
-static int make_single_plan(const mf_problem *pr, int device, mf_plan **out, std::vector<int32_t> &row,
-                            std::vector<int32_t> &col, std::vector<double> &val)
+static int make_single_plan(const mf_problem *pr, int device, mf_plan **out)
 {
 	if (!pr || pr->users < 0 || pr->items < 0 || pr->features < 1 || pr->nnz < 0 || pr->iters < 0 ||
 	    (pr->nnz > 0 && !pr->entries))
 		return MF_ERR_ARGUMENT;
-	try {
-		row.resize((size_t) pr->nnz);
-		col.resize((size_t) pr->nnz);
-		val.resize((size_t) pr->nnz);
-	} catch (const std::bad_alloc &) {
-		return MF_ERR_NO_MEMORY;
-	}
-	for (int64_t n = 0; n < pr->nnz; ++n) {
-		row[(size_t) n] = pr->entries[n].row;
-		col[(size_t) n] = pr->entries[n].col;
-		val[(size_t) n] = pr->entries[n].value;
-	}
 	mf_shard s;
 	memset(&s, 0, sizeof s);
 	s.users_total = pr->users;
@@ -548,21 +543,16 @@ static int make_single_plan(const mf_problem *pr, int device, mf_plan **out, std
 	s.user_begin = 0;
 	s.user_count = pr->users;
 	s.nnz = pr->nnz;
-	s.row = row.data();
-	s.col = col.data();
-	s.val = val.data();
 	s.alpha = pr->alpha;
 	s.device = device;
-	return mf_plan_create(out, &s);
+	return plan_create_impl(out, &s, pr->entries);
 }
 
 int mf_backend_run(const mf_problem *pr, double *L, double *R, int32_t *best, int device)
 {
 	if (!pr || !L || !R) return MF_ERR_ARGUMENT;   // L and R carry the initial factors in
 	mf_plan *p = nullptr;
-	std::vector<int32_t> row, col;
-	std::vector<double> val;
-	int rc = make_single_plan(pr, device, &p, row, col, val);
+	int rc = make_single_plan(pr, device, &p);
 	if (rc != MF_OK) return rc;
 	rc = mf_plan_upload_factors(p, L, R);
 	if (rc == MF_OK) rc = mf_plan_iterate(p, pr->iters);
@@ -583,9 +573,7 @@ int mf_backend_recommend(const mf_problem *pr, const double *L, const double *R,
 {
 	if (!pr || !L || !R || (!best && pr->users > 0)) return MF_ERR_ARGUMENT;
 	mf_plan *p = nullptr;
-	std::vector<int32_t> row, col;
-	std::vector<double> val;
-	int rc = make_single_plan(pr, device, &p, row, col, val);
+	int rc = make_single_plan(pr, device, &p);
 	if (rc != MF_OK) return rc;
 	rc = mf_plan_upload_factors(p, L, R);
 	if (rc == MF_OK) rc = mf_plan_recommend(p, best);
