@@ -318,7 +318,6 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 		const double est_us = (double) p->nnz * 8.0 * p->K / 6e12 * 1e6;
 		const int nc = (int) std::min<size_t>(32, (48 * 1024) / per_entry);
 		long long scratch_entries = 0;
-		(void) nl;
 		for (int kind = 0; kind < 2; ++kind) {
 			const std::vector<int> &pt = kind == 0 ? cptr : rptr;
 			const int nrows = kind == 0 ? p->items : p->uc;

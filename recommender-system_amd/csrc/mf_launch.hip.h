@@ -113,8 +113,8 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 	}
 	void *args[] = {&a};
 	if (p->n_long[kind] > 0) {
-		// extreme rows on the side stream, concurrently with the other rows on the main stream:
-		//   products kernel over their 256-entry segments -> ordered sum per (row, 16-column slice)
+		// extreme rows: products kernel over their 256-entry segments -> ordered sum per (row, column slice),
+		// beside the sweep of the other rows (schedule below)
 		mf::SweepArgs b = a;
 		b.nrows = p->n_seg[kind];
 		b.rowlist = nullptr;
