@@ -8,7 +8,7 @@ for thr in ${THRS:-default}; do
 import csv,glob,json
 f=glob.glob("$O/prof_nflx/*/*kernel_trace.csv")[0]
 rows=[r for r in csv.DictReader(open(f))]
-sw=[r for r in rows if "sweep" in r["Kernel_Name"] or "ordered" in r["Kernel_Name"]]
+sw=[r for r in rows if "mf::" in r["Kernel_Name"] and ("sweep" in r["Kernel_Name"] or "ordered" in r["Kernel_Name"])]
 j=json.load(open("$O/nflx_$thr.json"))
 print("threshold $thr: ms/iter %.2f item %.2f user %.2f  %s" % (j["ms_per_step"], j["roofline"]["item_sweep_ms"], j["roofline"]["user_sweep_ms"], j["roofline"]["kernel"].split("lds=")[1]))
 last=sw[-4:] if len(sw)>=4 else sw
