@@ -286,7 +286,9 @@ int mf_plan_iterate(mf_plan *p, int iters)
 	// number of iterations -- so the ping-pong parity returns to where it started -- into a HIP graph and replay it.
 	// Only for small sweeps; a large sweep is not launch-bound and a graph would pin its arguments for nothing.
 	const char *genv = getenv("MF_GRAPH");   // "0" disables
-	const bool small = (double) p->nnz * p->K < 2e6 && !p->timing && p->n_long[0] == 0 && p->n_long[1] == 0;
+	const char *gmax = getenv("MF_GRAPH_MAX");   // nnz*K below which iterations are replayed from a graph
+	const bool small = (double) p->nnz * p->K < (gmax ? atof(gmax) : 2e6) && !p->timing && p->n_long[0] == 0 &&
+	                   p->n_long[1] == 0;
 	constexpr int kGraphIters = 32;
 	if (small && iters >= 4 * kGraphIters && !(genv && genv[0] == '0')) {
 		hipGraph_t graph = nullptr;

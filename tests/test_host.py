@@ -235,3 +235,18 @@ def test_parallel_parser_equals_sequential_semantics(capi, orc, tmp_path):
     with pytest.raises(capi.ParseError) as e:       # %d reads 12, the next %d meets ".5" and fails
         capi.parse_text(odd)
     assert str(e.value) == "Error in non-zero entry."
+
+
+@pytest.mark.parametrize("shape", [(5000, 300, 37), (300, 9000, 20), (1, 70000, 3), (70000, 1, 2)])
+def test_parallel_init_equals_the_sequential_generator(capi, orc, shape):
+    """Above 65536 draws the initial factors are produced by several threads, each jumping its generator ahead
+    (matrix power of the lagged-Fibonacci recurrence): must equal glibc's srandom(0)/random() stream draw for draw
+    (the oracle calls libc), for whole instances and for user blocks."""
+    u, i, k = shape
+    L, R = capi.init_factors(u, i, k)
+    Lo, Ro = orc.init_factors(u, i, k)
+    assert np.array_equal(L, Lo) and np.array_equal(R, Ro)
+    u0, uc = u // 3, max(1, u // 2)
+    uc = min(uc, u - u0)
+    Lb, Rb = capi.init_factors_block(u, i, k, u0, uc)
+    assert np.array_equal(Lb, Lo[u0:u0 + uc]) and np.array_equal(Rb, Ro)
