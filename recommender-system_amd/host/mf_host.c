@@ -370,8 +370,8 @@ void mf_host_init_factors_block(int users, int items, int features, int u0, int 
 	const double norm = (double) features;
 	const uint64_t K = (uint64_t) features;
 	const int64_t draws = (int64_t) count * features + (R ? (int64_t) items * features : 0);
-	if (draws < (1 << 16)) {
-		/* small: one generator, in draw order */
+	if (draws < (1 << 22)) {
+		/* below ~4e6 draws (30 ms) one generator in draw order beats starting a thread team */
 		mf_rand g = g0;
 		for (int64_t u = 0; u < users; u++) {
 			if (u >= u0 && u < (int64_t) u0 + count) {
@@ -391,8 +391,14 @@ void mf_host_init_factors_block(int users, int items, int features, int u0, int 
 	mf_jump_table *tab = malloc(sizeof *tab);
 	if (!tab) abort();
 	jump_table_init(tab);
+	int want_threads = (int) (draws >> 20);   /* at least ~1e6 draws per thread, at most 32 threads */
+	if (want_threads > 32) want_threads = 32;
+	if (want_threads < 1) want_threads = 1;
+#ifdef _OPENMP
+	if (want_threads > omp_get_max_threads()) want_threads = omp_get_max_threads();
+#endif
 	/* L[u][k] in row-major draw order (mat2d.c:65-67): draw number u*K + k; rows of the block are cut over the threads */
-#pragma omp parallel
+#pragma omp parallel num_threads(want_threads)
 	{
 #ifdef _OPENMP
 		const int nt = omp_get_num_threads(), tid = omp_get_thread_num();

@@ -237,9 +237,9 @@ def test_parallel_parser_equals_sequential_semantics(capi, orc, tmp_path):
     assert str(e.value) == "Error in non-zero entry."
 
 
-@pytest.mark.parametrize("shape", [(5000, 300, 37), (300, 9000, 20), (1, 70000, 3), (70000, 1, 2)])
+@pytest.mark.parametrize("shape", [(150000, 3000, 37), (3000, 300000, 20), (1, 2200000, 3), (2200000, 1, 2)])
 def test_parallel_init_equals_the_sequential_generator(capi, orc, shape):
-    """Above 65536 draws the initial factors are produced by several threads, each jumping its generator ahead
+    """Above ~4e6 draws the initial factors are produced by several threads, each jumping its generator ahead
     (matrix power of the lagged-Fibonacci recurrence): must equal glibc's srandom(0)/random() stream draw for draw
     (the oracle calls libc), for whole instances and for user blocks."""
     u, i, k = shape
