@@ -176,6 +176,23 @@ typedef struct mf_candidate {
 	int32_t reserved;
 } mf_candidate;
 int mf_plan_recommend_scored(mf_plan *plan, mf_candidate *out);   /* user_count entries */
+/* the same for n listed users of this shard only (local ids); out[t] belongs to users[t] */
+int mf_plan_recommend_scored_users(mf_plan *plan, const int32_t *users, int32_t n, mf_candidate *out);
+
+/* Pass 1 alone, for a certification ACROSS the item blocks of a grid row: per user the best and second-best
+ * MATRIX-CORE (approximate) scores over this plan's unrated items, the arg-best (-1: none) and whether a
+ * non-finite score was seen; norm[i] = ||L[i]||_2; *rmax = max_j ||R[j]||_2 over this plan's items.  Any score
+ * is within 2*gamma_K*||l||*||r|| of the reference's, so with R = the largest rmax of the row and the margin
+ * thr_i = mf_backend_recommend_margin(K) * norm[i] * R:  best_w - max(second_w, best_c for c != w) > thr_i and no
+ * non-finite flag in any block  =>  arg_w IS the reference's answer.  Everyone else is re-scored exactly
+ * (mf_plan_recommend_scored_users) and merged as described above. */
+typedef struct mf_filter {
+	double best, second;
+	int32_t arg;
+	int32_t nonfinite;
+} mf_filter;
+int mf_plan_recommend_filter(mf_plan *plan, mf_filter *out, double *norm, double *rmax);
+double mf_backend_recommend_margin(int features);   /* 8 * (K + 8) * 2^-53 */
 
 /* Dense predictions of this shard's users, B (user_count x items, row-major) = L R^T exactly as mat2d_prod
  * (mat2d.c:100-113) forms them; for debug dumps of SMALL instances (user_count*items <= 2^26). */

@@ -31,6 +31,7 @@ HIP_SYMBOLS = [
     "mf_plan_download_factors", "mf_plan_iterate", "mf_plan_sweep_items", "mf_plan_sweep_users",
     "mf_plan_items_next", "mf_plan_items_current", "mf_plan_flip", "mf_plan_recommend", "mf_plan_recommend_info",
     "mf_plan_sweep_users_seeded", "mf_plan_users_next", "mf_plan_users_current", "mf_plan_recommend_scored",
+    "mf_plan_recommend_scored_users", "mf_plan_recommend_filter", "mf_backend_recommend_margin",
     "mf_plan_predict", "mf_plan_synchronize",
     "mf_plan_timing", "mf_plan_timing_read", "mf_plan_describe",
 ]
@@ -69,6 +70,8 @@ class Shard(C.Structure):  # mf_shard
 
 
 # mf_candidate: the partial scan state of mf_plan_recommend_scored, as a numpy record layout
+# mf_filter: pass-1 (matrix-core) report of mf_plan_recommend_filter
+FILTER_DTYPE = np.dtype([("best", np.float64), ("second", np.float64), ("arg", np.int32), ("nonfinite", np.int32)])
 CANDIDATE_DTYPE = np.dtype([("score", np.float64), ("best", np.int32), ("first", np.int32),
                             ("first_nan", np.int32), ("reserved", np.int32)])
 
@@ -122,6 +125,10 @@ def hip():
         lib.mf_plan_users_current.argtypes = [P]
         lib.mf_plan_users_current.restype = P
         lib.mf_plan_recommend_scored.argtypes = [P, P]
+        lib.mf_plan_recommend_scored_users.argtypes = [P, _i32p, C.c_int32, P]
+        lib.mf_plan_recommend_filter.argtypes = [P, P, _f64p, C.POINTER(C.c_double)]
+        lib.mf_backend_recommend_margin.argtypes = [C.c_int]
+        lib.mf_backend_recommend_margin.restype = C.c_double
         lib.mf_plan_recommend.argtypes = [P, _i32p]
         lib.mf_plan_recommend_info.argtypes = [P, C.POINTER(C.c_int64)]
         lib.mf_plan_predict.argtypes = [P, _f64p]
@@ -251,6 +258,11 @@ def partition_users(users, parts, row_ptr=None):
     if rc != 0:
         raise ValueError("mf_host_partition_users failed")
     return begin
+
+
+def recommend_margin(feats):
+    """8*(K+8)*2^-53: the factor of ||l||*||r|| above which a matrix-core score gap certifies the arg-max."""
+    return float(hip().mf_backend_recommend_margin(int(feats)))
 
 
 def balanced_grid(users, items, nproc):
@@ -408,6 +420,23 @@ class Plan:
         out = np.zeros(self.user_count, CANDIDATE_DTYPE)
         _check(hip().mf_plan_recommend_scored(self._h, out.ctypes.data), "mf_plan_recommend_scored")
         return out
+
+    def recommend_scored_users(self, users):
+        """The same for the listed users (local ids) only; record t belongs to users[t]."""
+        users = np.ascontiguousarray(users, np.int32)
+        out = np.zeros(users.shape[0], CANDIDATE_DTYPE)
+        _check(hip().mf_plan_recommend_scored_users(self._h, users, users.shape[0], out.ctypes.data),
+               "mf_plan_recommend_scored_users")
+        return out
+
+    def recommend_filter(self):
+        """Pass 1 alone: (FILTER_DTYPE records, ||L[i]|| per user, max ||R[j]|| over this plan's items)."""
+        out = np.zeros(self.user_count, FILTER_DTYPE)
+        norm = np.zeros(self.user_count, np.float64)
+        rmax = C.c_double()
+        _check(hip().mf_plan_recommend_filter(self._h, out.ctypes.data, norm, C.byref(rmax)),
+               "mf_plan_recommend_filter")
+        return out, norm, rmax.value
 
     def recommend_info(self):
         n = C.c_int64()

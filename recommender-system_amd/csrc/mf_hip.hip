@@ -168,6 +168,7 @@ void mf_plan_destroy(mf_plan *p)
 		(void) hipFree(p->Lbuf[1]);
 	}
 	(void) hipFree(p->cand_dev);
+	(void) hipFree(p->filt_dev);
 	if (!p->r_external) {
 		(void) hipFree(p->Rbuf[0]);
 		(void) hipFree(p->Rbuf[1]);
@@ -318,6 +319,86 @@ int mf_plan_iterate(mf_plan *p, int iters)
 	return iterate_eager(p, iters);
 }
 
+}   // extern "C"
+
+// Pass 1 of the recommendation: row norms + recommend_mfma_kernel.  filt == nullptr: the kernel certifies per user
+// against THIS plan's items (best / list of uncertain users); filt != nullptr: it only reports (best, second, arg,
+// non-finite flag) per user, for a certification over several item blocks by the caller (2-D tiles).
+static int launch_recommend_pass1(mf_plan *p, mf_filter *filt)
+{
+	const double *Lc = p->Lbuf[p->cur], *Rc = p->Rbuf[p->cur];
+	// pass 1: scores on the FP64 matrix cores + certification margin; pass 2: exact re-scoring of the rest
+	MF_HIP(hipMemsetAsync(p->rmax_bits, 0, sizeof(unsigned long long), p->stream));
+	MF_HIP(hipMemsetAsync(p->ucount, 0, sizeof(int), p->stream));
+	hipLaunchKernelGGL(mf::row_norm_kernel, dim3((p->uc + 63) / 64), dim3(64), 0, p->stream, Lc, p->uc,
+	                   p->K, p->lnorm, (unsigned long long *) nullptr);
+	if (p->items > 0)
+		hipLaunchKernelGGL(mf::row_norm_kernel, dim3((p->items + 63) / 64), dim3(64), 0, p->stream, Rc,
+		                   p->items, p->K, (double *) nullptr, p->rmax_bits);
+	mf::RecMfmaArgs m;
+	m.users = p->uc;
+	m.items = p->items;
+	m.K = p->K;
+	m.L = Lc;
+	m.R = Rc;
+	m.csr_ptr = p->csr_ptr;
+	m.csr_idx = p->csr_idx;
+	m.lnorm = p->lnorm;
+	m.rnorm_max_bits = p->rmax_bits;
+	m.thr_scale = mf_backend_recommend_margin(p->K);
+	m.best = p->best_dev;
+	m.ulist = p->ulist;
+	m.ucount = p->ucount;
+	m.filt = filt;
+	// Form.  The L block's image stays resident in LDS (it is the same for every item tile) whenever it fits
+	// beside the two R buffers, and the R chunks then go global -> LDS by LDS-DMA (even K): K <= 64 with 32-deep
+	// chunks, up to K = 100 with 24- or 20-deep ones -- the depth with the fewest chunks wins, an exact divisor
+	// of K on ties (K=100: 5 x 20 instead of 32+32+32+4).  Larger K: both operands staged through registers.
+	// Measured on 1e6 x 1e5 (profiles/r01/recommend_resident_L_ab.txt): K=100 55.4 vs 48.9 TFLOP/s, K=64 54.3
+	// vs 50.2, K=30 41.1 vs 37.7.
+	typedef void (*RecFn)(mf::RecMfmaArgs);
+	const bool vec = (p->K & 1) == 0;
+	const char *ares_env = getenv("MF_RECOMMEND_ARES");   // "0" disables the resident-L form (tests, A/B)
+	const char *bdma_env = getenv("MF_RECOMMEND_BDMA");   // "0": stage R chunks through registers (A/B)
+	const bool allow = !(ares_env && ares_env[0] == '0');
+	const bool allow_dma = vec && !(bdma_env && bdma_env[0] == '0');
+	const size_t static_lds = 8 * 1024, cu_lds = 160 * 1024;   // masks + merge arrays, rounded up
+	int kc = 32;
+	bool ares = false;
+	if (allow) {
+		int best_nch = 1 << 30;
+		for (int cand : {32, 24, 20}) {
+			if (cand == 24 && !allow_dma) continue;                    // 24 exists in the DMA form only
+			if (cand == 20 && p->K % 20 != 0 && !allow_dma) continue;   // register form: exact multiples only
+			if (mf::rec_mfma_lds(p->K, cand, true) + static_lds > cu_lds) continue;
+			const int nch = (p->K + cand - 1) / cand;
+			if (nch < best_nch || (nch == best_nch && p->K % cand == 0 && p->K % kc != 0)) {
+				best_nch = nch;
+				kc = cand;
+				ares = true;
+			}
+		}
+	}
+	const bool bdma = ares && allow_dma;
+	RecFn fn;
+	if (kc == 24)
+		fn = mf::recommend_mfma_kernel<true, 24, true, true>;
+	else if (kc == 20)   // even K here
+		fn = bdma ? mf::recommend_mfma_kernel<true, 20, true, true> : mf::recommend_mfma_kernel<true, 20, true, false>;
+	else if (bdma)
+		fn = mf::recommend_mfma_kernel<true, 32, true, true>;
+	else
+		fn = ares ? (vec ? mf::recommend_mfma_kernel<true, 32, true> : mf::recommend_mfma_kernel<false, 32, true>)
+		          : (vec ? mf::recommend_mfma_kernel<true, 32, false> : mf::recommend_mfma_kernel<false, 32, false>);
+	const size_t lds = mf::rec_mfma_lds(p->K, kc, ares);
+	MF_HIP(raise_lds_limit((const void *) fn, lds));
+	hipLaunchKernelGGL(fn, dim3((p->uc + mf::kMU - 1) / mf::kMU), dim3(mf::kMThreads), lds, p->stream, m);
+	MF_HIP(hipGetLastError());
+	return MF_OK;
+}
+
+extern "C" {
+
 int mf_plan_recommend(mf_plan *p, int32_t *best)
 {
 	if (!p || (!best && p->uc > 0)) return MF_ERR_ARGUMENT;
@@ -344,71 +425,10 @@ int mf_plan_recommend(mf_plan *p, int32_t *best)
 		p->last_uncertain = -1;
 	} else {
 		// pass 1: scores on the FP64 matrix cores + certification margin; pass 2: exact re-scoring of the rest
-		MF_HIP(hipMemsetAsync(p->rmax_bits, 0, sizeof(unsigned long long), p->stream));
-		MF_HIP(hipMemsetAsync(p->ucount, 0, sizeof(int), p->stream));
-		hipLaunchKernelGGL(mf::row_norm_kernel, dim3((p->uc + 63) / 64), dim3(64), 0, p->stream, ex.L, p->uc,
-		                   p->K, p->lnorm, (unsigned long long *) nullptr);
-		if (p->items > 0)
-			hipLaunchKernelGGL(mf::row_norm_kernel, dim3((p->items + 63) / 64), dim3(64), 0, p->stream, ex.R,
-			                   p->items, p->K, (double *) nullptr, p->rmax_bits);
-		mf::RecMfmaArgs m;
-		m.users = p->uc;
-		m.items = p->items;
-		m.K = p->K;
-		m.L = ex.L;
-		m.R = ex.R;
-		m.csr_ptr = p->csr_ptr;
-		m.csr_idx = p->csr_idx;
-		m.lnorm = p->lnorm;
-		m.rnorm_max_bits = p->rmax_bits;
-		m.thr_scale = 8.0 * (double) (p->K + 8) * 1.1102230246251565e-16;
-		m.best = p->best_dev;
-		m.ulist = p->ulist;
-		m.ucount = p->ucount;
-		// Form.  The L block's image stays resident in LDS (it is the same for every item tile) whenever it fits
-		// beside the two R buffers, and the R chunks then go global -> LDS by LDS-DMA (even K): K <= 64 with 32-deep
-		// chunks, up to K = 100 with 24- or 20-deep ones -- the depth with the fewest chunks wins, an exact divisor
-		// of K on ties (K=100: 5 x 20 instead of 32+32+32+4).  Larger K: both operands staged through registers.
-		// Measured on 1e6 x 1e5 (profiles/r01/recommend_resident_L_ab.txt): K=100 55.4 vs 48.9 TFLOP/s, K=64 54.3
-		// vs 50.2, K=30 41.1 vs 37.7.
-		typedef void (*RecFn)(mf::RecMfmaArgs);
-		const bool vec = (p->K & 1) == 0;
-		const char *ares_env = getenv("MF_RECOMMEND_ARES");   // "0" disables the resident-L form (tests, A/B)
-		const char *bdma_env = getenv("MF_RECOMMEND_BDMA");   // "0": stage R chunks through registers (A/B)
-		const bool allow = !(ares_env && ares_env[0] == '0');
-		const bool allow_dma = vec && !(bdma_env && bdma_env[0] == '0');
-		const size_t static_lds = 8 * 1024, cu_lds = 160 * 1024;   // masks + merge arrays, rounded up
-		int kc = 32;
-		bool ares = false;
-		if (allow) {
-			int best_nch = 1 << 30;
-			for (int cand : {32, 24, 20}) {
-				if (cand == 24 && !allow_dma) continue;                    // 24 exists in the DMA form only
-				if (cand == 20 && p->K % 20 != 0 && !allow_dma) continue;   // register form: exact multiples only
-				if (mf::rec_mfma_lds(p->K, cand, true) + static_lds > cu_lds) continue;
-				const int nch = (p->K + cand - 1) / cand;
-				if (nch < best_nch || (nch == best_nch && p->K % cand == 0 && p->K % kc != 0)) {
-					best_nch = nch;
-					kc = cand;
-					ares = true;
-				}
-			}
+		{
+			const int rc1 = launch_recommend_pass1(p, nullptr);
+			if (rc1 != MF_OK) return rc1;
 		}
-		const bool bdma = ares && allow_dma;
-		RecFn fn;
-		if (kc == 24)
-			fn = mf::recommend_mfma_kernel<true, 24, true, true>;
-		else if (kc == 20)   // even K here
-			fn = bdma ? mf::recommend_mfma_kernel<true, 20, true, true> : mf::recommend_mfma_kernel<true, 20, true, false>;
-		else if (bdma)
-			fn = mf::recommend_mfma_kernel<true, 32, true, true>;
-		else
-			fn = ares ? (vec ? mf::recommend_mfma_kernel<true, 32, true> : mf::recommend_mfma_kernel<false, 32, true>)
-			          : (vec ? mf::recommend_mfma_kernel<true, 32, false> : mf::recommend_mfma_kernel<false, 32, false>);
-		const size_t lds = mf::rec_mfma_lds(p->K, kc, ares);
-		MF_HIP(raise_lds_limit((const void *) fn, lds));
-		hipLaunchKernelGGL(fn, dim3((p->uc + mf::kMU - 1) / mf::kMU), dim3(mf::kMThreads), lds, p->stream, m);
-		MF_HIP(hipGetLastError());
 		int cnt = 0;
 		MF_HIP(hipMemcpyAsync(&cnt, p->ucount, sizeof(int), hipMemcpyDeviceToHost, p->stream));
 		MF_HIP(hipStreamSynchronize(p->stream));
@@ -451,6 +471,68 @@ int mf_plan_recommend_scored(mf_plan *p, mf_candidate *out)
 	MF_HIP(hipGetLastError());
 	MF_HIP(hipMemcpyAsync(out, p->cand_dev, (size_t) p->uc * sizeof(mf_candidate), hipMemcpyDeviceToHost, p->stream));
 	MF_HIP(hipStreamSynchronize(p->stream));
+	return MF_OK;
+}
+
+int mf_plan_recommend_scored_users(mf_plan *p, const int32_t *users, int32_t n, mf_candidate *out)
+{
+	if (!p || n < 0 || (n > 0 && (!users || !out)) || n > p->uc) return MF_ERR_ARGUMENT;
+	if (!p->have_factors) return MF_ERR_STATE;
+	for (int32_t t = 0; t < n; ++t)
+		if (users[t] < 0 || users[t] >= p->uc) return MF_ERR_ARGUMENT;
+	MF_HIP(hipSetDevice(p->device));
+	if (n == 0) return MF_OK;
+	if (!p->cand_dev) {
+		const int rc = dev_alloc(&p->cand_dev, (size_t) p->uc);
+		if (rc != MF_OK) return rc;
+	}
+	MF_HIP(hipMemcpyAsync(p->ulist, users, (size_t) n * sizeof(int), hipMemcpyHostToDevice, p->stream));
+	mf::RecArgs ex;
+	ex.users = n;
+	ex.items = p->items;
+	ex.K = p->K;
+	ex.L = p->Lbuf[p->cur];
+	ex.R = p->Rbuf[p->cur];
+	ex.csr_ptr = p->csr_ptr;
+	ex.csr_idx = p->csr_idx;
+	ex.best = p->best_dev;
+	ex.ulist = p->ulist;
+	ex.cand = p->cand_dev;   // written at the user's own index
+	hipLaunchKernelGGL(mf::recommend_kernel, dim3((n + mf::kRT - 1) / mf::kRT), dim3(256), 0, p->stream, ex);
+	MF_HIP(hipGetLastError());
+	std::vector<mf_candidate> all;
+	try {
+		all.resize((size_t) p->uc);
+	} catch (const std::bad_alloc &) {
+		return MF_ERR_NO_MEMORY;
+	}
+	MF_HIP(hipMemcpyAsync(all.data(), p->cand_dev, (size_t) p->uc * sizeof(mf_candidate), hipMemcpyDeviceToHost, p->stream));
+	MF_HIP(hipStreamSynchronize(p->stream));
+	for (int32_t t = 0; t < n; ++t) out[t] = all[(size_t) users[t]];
+	return MF_OK;
+}
+
+double mf_backend_recommend_margin(int features) { return 8.0 * (double) (features + 8) * 1.1102230246251565e-16; }
+
+int mf_plan_recommend_filter(mf_plan *p, mf_filter *out, double *norm, double *rmax)
+{
+	if (!p || (p->uc > 0 && (!out || !norm)) || !rmax) return MF_ERR_ARGUMENT;
+	if (!p->have_factors) return MF_ERR_STATE;
+	MF_HIP(hipSetDevice(p->device));
+	*rmax = 0.0;
+	if (p->uc == 0) return MF_OK;
+	if (!p->filt_dev) {
+		const int rc = dev_alloc(&p->filt_dev, (size_t) p->uc);
+		if (rc != MF_OK) return rc;
+	}
+	const int rc = launch_recommend_pass1(p, p->filt_dev);
+	if (rc != MF_OK) return rc;
+	unsigned long long bits = 0;
+	MF_HIP(hipMemcpyAsync(out, p->filt_dev, (size_t) p->uc * sizeof(mf_filter), hipMemcpyDeviceToHost, p->stream));
+	MF_HIP(hipMemcpyAsync(norm, p->lnorm, (size_t) p->uc * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+	MF_HIP(hipMemcpyAsync(&bits, p->rmax_bits, sizeof bits, hipMemcpyDeviceToHost, p->stream));
+	MF_HIP(hipStreamSynchronize(p->stream));
+	memcpy(rmax, &bits, sizeof bits);   // a NaN norm arrives as NaN: the caller then certifies nobody
 	return MF_OK;
 }
 

@@ -213,6 +213,7 @@ struct RecMfmaArgs {
 	int *__restrict__ best;
 	int *__restrict__ ulist;                   // out: users that need the exact pass
 	int *__restrict__ ucount;
+	mf_filter *__restrict__ filt;              // optional: report (best, second, arg, non-finite) instead of certifying
 };
 
 __global__ void __launch_bounds__(kWave) row_norm_kernel(const double *__restrict__ X, int rows, int K,
@@ -546,6 +547,10 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 		const Top2 o{red_b1[tid][1], red_b2[tid][1], red_i1[tid][1]};
 		top2_merge(t, o);
 		const int bd = red_bad[tid][0] | red_bad[tid][1];
+		if (a.filt) {   // certification is the caller's, over several item blocks
+			a.filt[i0 + tid] = mf_filter{t.b1, t.b2, t.i1, bd};
+			return;
+		}
 		const double rmax = __longlong_as_double((long long) *a.rnorm_max_bits);
 		const double thr = a.thr_scale * a.lnorm[i0 + tid] * rmax + 1e-300;
 		const bool certain = !bd && (t.i1 < 0 || (t.b1 - t.b2) > thr);

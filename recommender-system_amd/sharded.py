@@ -145,6 +145,29 @@ def merge_candidates(left, right):
     return out
 
 
+def certify_filters(filters, norm, rmax, margin):
+    """Certification of the matrix-core pass over the item blocks of one grid row (mf_filter records per block, in
+    item order, arg already GLOBAL).  Returns (answer, certain): for certain users `answer` is the reference's
+    arg-max (-1: nothing unrated); the others must be re-scored exactly.  A score differs from the reference's by
+    less than half the margin, so the winning block's best must beat its own runner-up AND every other block's best
+    by margin * ||L[i]|| * max ||R[j]||; any non-finite score, or a non-finite norm, certifies nobody."""
+    best = np.stack([f["best"] for f in filters])          # blocks x users
+    w = np.argmax(best, axis=0)
+    cols = np.arange(best.shape[1])
+    b1 = best[w, cols]
+    others = best.copy()
+    others[w, cols] = -np.inf
+    runner = np.maximum(np.stack([f["second"] for f in filters])[w, cols], others.max(axis=0))
+    arg = np.stack([f["arg"] for f in filters])[w, cols]
+    bad = np.stack([f["nonfinite"] for f in filters]).any(axis=0)
+    thr = margin * norm * rmax + 1e-300
+    with np.errstate(invalid="ignore"):
+        gap_ok = (b1 - runner) > thr                        # False for NaN thresholds and for -inf - -inf
+    none = np.stack([f["arg"] for f in filters]).max(axis=0) < 0
+    certain = ~bad & (none | ((arg >= 0) & gap_ok))
+    return np.where(none, -1, arg).astype(np.int32), certain
+
+
 def finish_candidates(c):
     """best[i] of print_output: -1 without an unrated item; the first unrated item when its score is NaN
     (nothing compares greater than NaN); else the arg-max over the non-NaN scores."""
@@ -206,22 +229,57 @@ class GridFactorization:
         for _ in range(iters):
             self.step()
 
-    def gather_recommendations(self, users_total, user_begin, item_begin):
-        """Every tile scans its item block; the states of a grid row are merged in item order and the user
-        blocks concatenated.  Every rank returns the full list (small: one int per user)."""
-        world = self.grid[0] * self.grid[1]
-        cand = self.plan.recommend_scored()
+    def gather_recommendations(self, users_total, user_begin, item_begin, use_filter=True):
+        """Every tile runs the matrix-core pass over its item block; a user is settled when the winning block's
+        best beats every other candidate of the grid row by the rounding margin (certify_filters).  The others are
+        re-scored exactly in every tile of the row and the partial scan states merged in item order -- the
+        MPI_Reduce(max_cmp) of matFact-mpi.c:98 with the serial program's tie and NaN rules.  Every rank returns
+        the full list (one int per user)."""
+        rows, cols = self.grid
+        world = rows * cols
         j0 = int(item_begin[self.gc])
-        for f in ("best", "first"):
-            cand[f][cand[f] >= 0] += j0
-        parts = [cand]
+        margin = None
+        if use_filter and hasattr(self.plan, "recommend_filter"):
+            from . import capi
+            filt, norm, rmax = self.plan.recommend_filter()
+            filt["arg"][filt["arg"] >= 0] += j0
+            margin = capi.recommend_margin(self.plan.feats)
+            mine = (filt, norm, rmax)
+        else:
+            mine = None
+        parts = [mine]
         if world > 1:
             parts = [None] * world
-            dist.all_gather_object(parts, cand)
-        out = np.empty(users_total, np.int32)
-        for gr in range(self.grid[0]):
-            acc = parts[gr * self.grid[1]]
-            for gc in range(1, self.grid[1]):
-                acc = merge_candidates(acc, parts[gr * self.grid[1] + gc])
-            out[user_begin[gr]:user_begin[gr + 1]] = finish_candidates(acc)
+            dist.all_gather_object(parts, mine)
+        out = np.full(users_total, -1, np.int32)
+        uncertain = {}                      # grid row -> local user ids that need the exact pass
+        for gr in range(rows):
+            n = int(user_begin[gr + 1] - user_begin[gr])
+            if mine is None:
+                uncertain[gr] = np.arange(n, dtype=np.int32)
+                continue
+            blocks = [parts[gr * cols + gc] for gc in range(cols)]
+            ans, certain = certify_filters([b[0] for b in blocks], blocks[0][1], max(b[2] for b in blocks), margin)
+            out[user_begin[gr]:user_begin[gr + 1]] = ans
+            uncertain[gr] = np.flatnonzero(~certain).astype(np.int32)
+        self.last_uncertain = int(sum(len(v) for v in uncertain.values()))
+        # exact pass for the uncertain users of MY grid row, in my item block; merged over the row in item order
+        todo = uncertain[self.gr]
+        if hasattr(self.plan, "recommend_scored_users"):
+            cand = self.plan.recommend_scored_users(todo)
+        else:
+            cand = self.plan.recommend_scored()[todo]
+        for f in ("best", "first"):
+            cand[f][cand[f] >= 0] += j0
+        cparts = [cand]
+        if world > 1:
+            cparts = [None] * world
+            dist.all_gather_object(cparts, cand)
+        for gr in range(rows):
+            if len(uncertain[gr]) == 0:
+                continue
+            acc = cparts[gr * cols]
+            for gc in range(1, cols):
+                acc = merge_candidates(acc, cparts[gr * cols + gc])
+            out[user_begin[gr] + uncertain[gr]] = finish_candidates(acc)
         return out

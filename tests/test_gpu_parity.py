@@ -699,3 +699,48 @@ def test_power_law_extreme_path_equals_plain_path_at_scale(capi, monkeypatch):
         plan.close()
         assert ("long_rows=0/0" in desc) == (mode == "plain"), desc
     assert np.array_equal(got["split"][0], got["plain"][0]) and np.array_equal(got["split"][1], got["plain"][1])
+
+
+def test_grid_recommend_filter_then_exact_equals_serial(capi, orc):
+    """The certified form of the grid recommendation on one GPU: mf_plan_recommend_filter per item block,
+    certify_filters across the blocks, mf_plan_recommend_scored_users + merge for the rest == the serial scan.
+    Planted: exact ties across blocks, 1-ulp neighbours, NaN / inf scores, fully rated users and blocks."""
+    import importlib
+    sh = importlib.import_module("recommender_system_amd.sharded")
+    u, i, k = 300, 420, 24
+    rng = np.random.default_rng(17)
+    L = rng.standard_normal((u, k))
+    R = rng.standard_normal((i, k))
+    R[400] = R[10]                 # exact tie across item blocks: the lower index must win
+    R[130] = R[129]                # tie inside a block
+    R[301] = np.nextafter(R[300], np.inf)
+    L[9, :] = np.nan
+    d = random_instance(31, u, i, k, density=0.25, full_rows=(5, 66), empty_rows=(6,))
+    margin = capi.recommend_margin(k)
+    for ib, poison in (([0, 420], False), ([0, 128, 256, 420], False), ([0, 11, 401, 420], False),
+                       ([0, 128, 256, 420], True)):
+        if poison:
+            R[200, 0] = np.inf     # an infinite norm poisons the margin: nobody is certified, everything exact
+        want = orc.recommend(orc.Instance(**d), L, R)
+        plans, filts = [], []
+        for c in range(len(ib) - 1):
+            sel = (d["col"] >= ib[c]) & (d["col"] < ib[c + 1])
+            plan = capi.Plan(u, ib[c + 1] - ib[c], k, 0.0, d["row"][sel], d["col"][sel] - np.int32(ib[c]), d["val"][sel])
+            plan.upload(L, np.ascontiguousarray(R[ib[c]:ib[c + 1]]))
+            f, norm, rmax = plan.recommend_filter()
+            f["arg"][f["arg"] >= 0] += ib[c]
+            plans.append(plan)
+            filts.append((f, norm, rmax))
+        ans, certain = sh.certify_filters([f[0] for f in filts], filts[0][1], max(f[2] for f in filts), margin)
+        todo = np.flatnonzero(~certain).astype(np.int32)
+        assert 9 in todo                                     # the NaN user is never certified
+        assert (len(todo) == u - 2) if poison else (0 < len(todo) < u // 2), len(todo)   # 5 and 66 have nothing unrated
+        acc = None
+        for c, plan in enumerate(plans):
+            cand = plan.recommend_scored_users(todo)
+            for f in ("best", "first"):
+                cand[f][cand[f] >= 0] += ib[c]
+            acc = cand if acc is None else sh.merge_candidates(acc, cand)
+            plan.close()
+        ans[todo] = sh.finish_candidates(acc)
+        assert np.array_equal(ans, want), ib

@@ -269,3 +269,43 @@ def test_balanced_grid_rule():
     for n in range(1, 40):
         r, c = g(1000, 30, n)
         assert r * c == n and r >= c
+
+
+def test_filter_certification_over_item_blocks():
+    """certify_filters: a user is settled only when the winning block's best beats its own runner-up and every
+    other block's best by the margin; ties across blocks, near-ties, NaN/inf scores, NaN norms and fully rated
+    users must all come back uncertain or exactly right."""
+    import recommender_system_amd as rs
+    sh = __import__("importlib").import_module("recommender_system_amd.sharded")
+    rng = np.random.default_rng(11)
+    users, items, cuts = 200, 40, [0, 13, 14, 40]
+    S = rng.standard_normal((users, items))
+    rated = rng.random((users, items)) < 0.3
+    rated[3] = True                                  # nothing unrated at all
+    rated[4, :14] = True                             # whole blocks rated
+    S[5, 20] = S[5, 2] = S[5].max() + 1.0            # exact tie across blocks
+    S[6, 30] = S[6].max() + 2.0
+    S[6, 1] = S[6, 30] - 1e-13                       # near-tie below the margin
+    S[7, 9] = np.nan
+    S[8, 25] = np.inf
+    rated[5, [2, 20]] = rated[6, [1, 30]] = rated[7, 9] = rated[8, 25] = False
+    norm = np.ones(users)
+    norm[9] = np.nan
+    filters = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        f = np.zeros(users, rs.capi.FILTER_DTYPE)
+        for i in range(users):
+            v = [(S[i, j], j) for j in range(a, b) if not rated[i, j]]
+            fin = sorted([x for x in v if np.isfinite(x[0])], key=lambda x: (-x[0], x[1]))
+            f[i] = (fin[0][0] if fin else -np.inf, fin[1][0] if len(fin) > 1 else -np.inf,
+                    fin[0][1] if fin else -1, int(any(not np.isfinite(x[0]) for x in v)))
+        filters.append(f)
+    ans, certain = sh.certify_filters(filters, norm, 1.0, 1e-9)
+    for i in range(users):
+        want = scan_state(S[i], rated[i])
+        want = -1 if want[2] < 0 else (want[2] if want[3] else want[1])
+        if certain[i]:
+            assert ans[i] == want, i
+    assert certain[3] and ans[3] == -1
+    assert not certain[5] and not certain[6] and not certain[7] and not certain[8] and not certain[9]
+    assert certain.sum() > users * 0.9
