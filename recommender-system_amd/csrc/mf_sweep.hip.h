@@ -462,6 +462,114 @@ __global__ void __launch_bounds__(kWave) ordered_sum_kernel(OrderedSumArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Resident form for TOY instances (the reference's inst0/1/2: a handful of rows, up to 1e5 iterations): everything -- both generations of L and R and the CSR/CSC entries -- fits the LDS of ONE
+// workgroup, so the whole iteration loop runs inside one launch with a workgroup barrier per iteration
+// instead of two dependent kernel launches (~3.4 us each even when replayed from a graph).  Thread t owns
+// factor row t (users first, then items) and walks its entries in file order: the same owner-computes
+// arithmetic and order as the sweep kernels, so the result is the same bits.
+// ------------------------------------------------------------------------------------------------
+struct ResidentArgs {
+	int users, items, K, iters;
+	double c2;                                  // alpha * 2
+	const int *__restrict__ csr_ptr;            // users + 1
+	const int *__restrict__ csr_idx;            // item ids
+	const double *__restrict__ csr_val;
+	const int *__restrict__ csc_ptr;            // items + 1
+	const int *__restrict__ csc_idx;            // local user ids
+	const double *__restrict__ csc_val;
+	const double *__restrict__ L_in;            // current generation
+	const double *__restrict__ R_in;
+	double *__restrict__ L_out;                 // where the generation after `iters` iterations belongs
+	double *__restrict__ R_out;
+	int nnz;
+};
+
+constexpr size_t resident_lds_bytes(int users, int items, int K, long long nnz)
+{
+	return (size_t) 2 * (size_t) (users + items) * K * 8 + (size_t) nnz * 2 * 12 + (size_t) (users + items + 2) * 4 + 64;
+}
+
+// KMAX > 0: K <= KMAX and the owner keeps its old row and its accumulators in registers (loops fully unrolled, the
+// K loads of a gathered row issued together: one LDS latency per entry instead of one per element); KMAX == 0: any K.
+template <int KMAX>
+__global__ void __launch_bounds__(1024) sweep_resident_kernel(ResidentArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) char rlds[];
+	const int U = a.users, I = a.items, K = a.K, nnz = a.nnz;
+	const int nf = (U + I) * K;                 // doubles per generation: L rows, then R rows
+	double *gen0 = reinterpret_cast<double *>(rlds), *gen1 = gen0 + nf;
+	double *val = gen1 + nf;                    // [csr values | csc values]
+	int *idx = reinterpret_cast<int *>(val + 2 * (size_t) nnz);   // [csr idx | csc idx]
+	int *ptr = idx + 2 * (size_t) nnz;          // [csr_ptr (U+1) | csc_ptr (I+1)]
+	const int t = threadIdx.x, nt = blockDim.x;
+	for (int x = t; x < U * K; x += nt) gen0[x] = a.L_in[x];
+	for (int x = t; x < I * K; x += nt) gen0[U * K + x] = a.R_in[x];
+	for (int x = t; x < nnz; x += nt) {
+		val[x] = a.csr_val[x];
+		val[nnz + x] = a.csc_val[x];
+		idx[x] = a.csr_idx[x];
+		idx[nnz + x] = a.csc_idx[x];
+	}
+	for (int x = t; x <= U; x += nt) ptr[x] = a.csr_ptr[x];
+	for (int x = t; x <= I; x += nt) ptr[U + 1 + x] = a.csc_ptr[x];
+	__syncthreads();
+
+	// thread t < U: user row t against R (CSR); U <= t < U+I: item row t-U against L (CSC)
+	const bool user = t < U, owner = t < U + I;
+	const int r = user ? t : t - U;
+	const int beg = owner ? (user ? ptr[r] : nnz + ptr[U + 1 + r]) : 0;
+	const int end = owner ? (user ? ptr[r + 1] : nnz + ptr[U + 1 + r + 1]) : 0;
+	const int xoff = (user ? r : U + r) * K;    // my row inside a generation
+	const int ybase = user ? U * K : 0;         // the other factor inside a generation
+	double *cur = gen0, *nxt = gen1;
+	for (int it = 0; it < a.iters; ++it) {
+		if (owner && KMAX > 0) {
+			constexpr int KM = KMAX > 0 ? KMAX : 1;
+			double xr[KM], acc[KM];
+#pragma unroll
+			for (int k = 0; k < KM; ++k) {
+				xr[k] = k < K ? cur[xoff + k] : 0.0;
+				acc[k] = xr[k];
+			}
+			for (int n = beg; n < end; ++n) {
+				const double *y = cur + ybase + idx[n] * K;
+				double yr[KM];
+#pragma unroll
+				for (int k = 0; k < KM; ++k) yr[k] = k < K ? y[k] : 0.0;
+				double dot = 0.0;
+#pragma unroll
+				for (int k = 0; k < KM; ++k)
+					if (k < K) dot = dot + xr[k] * yr[k];
+				const double e = a.c2 * (val[n] - dot);
+#pragma unroll
+				for (int k = 0; k < KM; ++k)
+					if (k < K) acc[k] = acc[k] + e * yr[k];
+			}
+#pragma unroll
+			for (int k = 0; k < KM; ++k)
+				if (k < K) nxt[xoff + k] = acc[k];
+		} else if (owner) {
+			const double *x = cur + xoff;
+			double *xn = nxt + xoff;
+			for (int k = 0; k < K; ++k) xn[k] = x[k];
+			for (int n = beg; n < end; ++n) {
+				const double *y = cur + ybase + idx[n] * K;
+				double dot = 0.0;
+				for (int k = 0; k < K; ++k) dot = dot + x[k] * y[k];
+				const double e = a.c2 * (val[n] - dot);
+				for (int k = 0; k < K; ++k) xn[k] = xn[k] + e * y[k];
+			}
+		}
+		__syncthreads();
+		double *sw = cur;
+		cur = nxt;
+		nxt = sw;
+	}
+	for (int x = t; x < U * K; x += nt) a.L_out[x] = cur[x];
+	for (int x = t; x < I * K; x += nt) a.R_out[x] = cur[U * K + x];
+}
+
+// ------------------------------------------------------------------------------------------------
 // Sweep kernel, row-cooperative form: for launches with FEW rows (ML100k: 943 users / 1682 items), where
 // one wave walking a long row alone (737 entries = 47 chunks) is the whole launch time.  A workgroup of
 // 8 waves owns one row.  Waves 1..7 ("producers") each take one chunk per round: LDS-DMA gather, phase A

@@ -744,3 +744,24 @@ def test_grid_recommend_filter_then_exact_equals_serial(capi, orc):
             plan.close()
         ans[todo] = sh.finish_candidates(acc)
         assert np.array_equal(ans, want), ib
+
+
+@pytest.mark.parametrize("shape", [(5, 6, 3, 0.4, 9), (6, 5, 12, 0.6, 10), (4, 4, 30, 0.6, 33), (3, 3, 40, 0.8, 8),
+                                   (1, 1, 2, 1.0, 15), (7, 2, 5, 0.5, 101)])
+def test_resident_toy_kernel_bit_exact(capi, orc, shape, monkeypatch):
+    """sweep_resident_kernel (whole iteration loop inside one workgroup, every register-row variant and the generic
+    one, odd and even iteration counts) against the oracle and against the ordinary two-launch path."""
+    u, i, k, dens, iters = shape
+    d = random_instance(500 + u + k, u, i, k, density=dens, iters=iters, alpha=0.01)
+    assert len(d["row"]) * k <= 512
+    inst = _inst(capi, d)
+    L0, R0 = capi.init_factors(u, i, k)
+    Lo, Ro = L0.copy(), R0.copy()
+    orc.factorize(orc.Instance(**d), Lo, Ro)
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MF_RESIDENT", mode)
+        L, R = L0.copy(), R0.copy()
+        capi.backend_factorize(inst, L, R)
+        got[mode] = (L, R)
+        assert np.array_equal(L, Lo) and np.array_equal(R, Ro), (shape, mode)
