@@ -78,6 +78,10 @@ int mf_backend_recommend(const mf_problem *p, const double *L, const double *R, 
  * (either may be NULL if the caller does not want them back). */
 int mf_backend_run(const mf_problem *p, double *L, double *R, int32_t *best, int device);
 
+/* The same when only the recommendation list is wanted -- what the reference's main prints (matFact.c:127):
+ * the initial factors go in, nothing but best[] comes back (no device-to-host copy of L and R). */
+int mf_backend_run_top1(const mf_problem *p, const double *L0, const double *R0, int32_t *best, int device);
+
 /* The same on several GPUs of ONE process: users are cut into ndev contiguous blocks balanced by entry count,
  * L blocks are private, R is replicated and summed after every item sweep by a peer-to-peer reduce over xGMI
  * (the decomposition of matFact-mpi.c:155-214 with the 8x1 grid of mpiutil.c:54-88).  devices[] lists HIP

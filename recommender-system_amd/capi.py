@@ -26,7 +26,7 @@ MF_ERR_ARGUMENT, MF_ERR_NO_DEVICE, MF_ERR_HIP, MF_ERR_NO_MEMORY, MF_ERR_UNSUPPOR
 # every symbol include/matfact_hip.h declares (tests check the library exports each one)
 HIP_SYMBOLS = [
     "mf_backend_strerror", "mf_backend_last_hip_error", "mf_backend_abi_version", "mf_backend_device_count",
-    "mf_backend_factorize", "mf_backend_recommend", "mf_backend_run", "mf_backend_run_multi",
+    "mf_backend_factorize", "mf_backend_recommend", "mf_backend_run", "mf_backend_run_multi", "mf_backend_run_top1",
     "mf_plan_create", "mf_plan_destroy", "mf_plan_set_stream", "mf_plan_upload_factors",
     "mf_plan_download_factors", "mf_plan_iterate", "mf_plan_sweep_items", "mf_plan_sweep_users",
     "mf_plan_items_next", "mf_plan_items_current", "mf_plan_flip", "mf_plan_recommend", "mf_plan_recommend_info",
@@ -103,6 +103,7 @@ def hip():
         lib.mf_backend_last_hip_error.restype = C.c_char_p
         lib.mf_backend_run.argtypes = [C.POINTER(Problem), _f64p, _f64p, _i32p, C.c_int]
         lib.mf_backend_run_multi.argtypes = [C.POINTER(Problem), _f64p, _f64p, _i32p, _i32p, C.c_int]
+        lib.mf_backend_run_top1.argtypes = [C.POINTER(Problem), _f64p, _f64p, _i32p, C.c_int]
         lib.mf_backend_factorize.argtypes = [C.POINTER(Problem), _f64p, _f64p, C.c_int]
         lib.mf_backend_recommend.argtypes = [C.POINTER(Problem), _f64p, _f64p, _i32p, C.c_int]
         lib.mf_plan_create.argtypes = [C.POINTER(P), C.POINTER(Shard)]
@@ -322,6 +323,14 @@ def backend_run_multi(inst, L, R, devices, iters=None):
     best = np.empty(inst.users, np.int32)
     dev = np.ascontiguousarray(devices, np.int32)
     _check(hip().mf_backend_run_multi(C.byref(p), L, R, best, dev, len(dev)), "mf_backend_run_multi")
+    return best
+
+
+def backend_run_top1(inst, L0, R0, iters=None, device=0):
+    """mf_backend_run_top1: initial factors in, only the recommendation list out."""
+    p, keep = _problem(inst, iters)
+    best = np.empty(inst.users, np.int32)
+    _check(hip().mf_backend_run_top1(C.byref(p), L0, R0, best, device), "mf_backend_run_top1")
     return best
 
 

@@ -689,6 +689,19 @@ int mf_backend_run(const mf_problem *pr, double *L, double *R, int32_t *best, in
 	return rc;
 }
 
+int mf_backend_run_top1(const mf_problem *pr, const double *L0, const double *R0, int32_t *best, int device)
+{
+	if (!pr || !L0 || !R0 || (!best && pr->users > 0)) return MF_ERR_ARGUMENT;
+	mf_plan *p = nullptr;
+	int rc = make_single_plan(pr, device, &p);
+	if (rc != MF_OK) return rc;
+	rc = mf_plan_upload_factors(p, L0, R0);
+	if (rc == MF_OK) rc = mf_plan_iterate(p, pr->iters);
+	if (rc == MF_OK) rc = mf_plan_recommend(p, best);
+	mf_plan_destroy(p);
+	return rc;
+}
+
 #include "mf_multi.hip.h"
 
 int mf_backend_factorize(const mf_problem *pr, double *L, double *R, int device)

@@ -184,7 +184,7 @@ int main(int argc, char **argv)
 		}
 		rc = mf_backend_run_multi(&prob, L, R, best, devs, nd);
 	} else {
-		rc = mf_backend_run(&prob, L, R, best, device);
+		rc = mf_backend_run_top1(&prob, L, R, best, device);   /* only the list is printed: no copy-back of L and R */
 	}
 	if (rc != MF_OK) {
 		fprintf(stderr, "matFact (hip backend): %s %s\n", mf_backend_strerror(rc),

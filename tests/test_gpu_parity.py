@@ -765,3 +765,16 @@ def test_resident_toy_kernel_bit_exact(capi, orc, shape, monkeypatch):
         capi.backend_factorize(inst, L, R)
         got[mode] = (L, R)
         assert np.array_equal(L, Lo) and np.array_equal(R, Ro), (shape, mode)
+
+
+def test_run_top1_gives_the_list_of_the_full_run(capi, orc):
+    """mf_backend_run_top1 (what the CLI calls: no copy-back of L and R) == mf_backend_run's list == the oracle's;
+    the initial factors handed in stay untouched."""
+    d = random_instance(77, 60, 45, 10, density=0.3, iters=25, alpha=0.002)
+    inst = _inst(capi, d)
+    L0, R0 = capi.init_factors(60, 45, 10)
+    Lc, Rc = L0.copy(), R0.copy()
+    best = capi.backend_run_top1(inst, Lc, Rc)
+    assert np.array_equal(Lc, L0) and np.array_equal(Rc, R0)
+    Lo, Ro, bo = orc.run(orc.Instance(**d))
+    assert np.array_equal(best, bo)

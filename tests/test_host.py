@@ -20,10 +20,10 @@ def test_libraries_export_every_declared_symbol(capi):
         assert hasattr(host, s), s
     # and the header declares exactly that list
     hdr = open(os.path.join(ROOT, "include", "matfact_hip.h")).read()
-    declared = set(re.findall(r"\b(mf_(?:backend|plan)_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(mf_(?:backend|plan)_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(capi.HIP_SYMBOLS)
     hdr = open(os.path.join(ROOT, "include", "matfact_host.h")).read()
-    declared = set(re.findall(r"\b(mf_host_[a-z_]+)\s*\(", hdr)) - {
+    declared = set(re.findall(r"\b(mf_host_[a-z0-9_]+)\s*\(", hdr)) - {
         "mf_host_block_low", "mf_host_block_high", "mf_host_block_size", "mf_host_block_owner"}
     assert declared == set(capi.HOST_SYMBOLS)
     assert capi.hip().mf_backend_abi_version() == 2
