@@ -231,7 +231,21 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 				nx_idx = a.idx[c + nch + lane];
 				nx_val = a.val[c + nch + lane];
 			}
-			// ---- stage: one DMA per gathered row and pass
+			// ---- stage.  Short rows with an odd number of 16-B pieces (K = 10, 30, 50: the tile rows are then
+			// contiguous, S = 16 P) are gathered SEVERAL per instruction -- lane -> (row lane / P, piece lane % P),
+			// 12 rows at K=10 -- instead of one instruction with five active lanes per row.
+			constexpr bool kMultiRow = KT > 0 && ((KT / 2) & 1) == 1 && KT / 2 <= 32;
+			if constexpr (kMultiRow) {
+				constexpr int PP = KT / 2, RPI = kWave / PP;   // pieces per row, rows per instruction
+				const int rr = lane / PP, piece = lane - rr * PP;
+				for (int n0 = 0; n0 < cnt; n0 += RPI) {
+					const int n = n0 + rr;
+					const int j = __shfl(my_idx, n < cnt ? n : 0);
+					const char *src = reinterpret_cast<const char *>(ybase) + (size_t) (unsigned) j * (size_t) (KT * 8) + 16 * piece;
+					if (rr < RPI && n < cnt)
+						__builtin_amdgcn_global_load_lds((mf_gvoid *) src, (mf_lvoid *) (tile + n0 * S), 16, 0, 0);
+				}
+			} else
 			for (int n = 0; n < cnt; ++n) {
 				const int j = __builtin_amdgcn_readlane(my_idx, n);
 				unsigned long long base = ybase + (unsigned long long) (unsigned) j * (unsigned long long) (K * 8);
