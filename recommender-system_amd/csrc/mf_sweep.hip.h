@@ -231,18 +231,18 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 				nx_idx = a.idx[c + nch + lane];
 				nx_val = a.val[c + nch + lane];
 			}
-			// ---- stage.  Short rows with an odd number of 16-B pieces (K = 10, 30, 50: the tile rows are then
-			// contiguous, S = 16 P) are gathered SEVERAL per instruction -- lane -> (row lane / P, piece lane % P),
-			// 12 rows at K=10 -- instead of one instruction with five active lanes per row.
-			constexpr bool kMultiRow = KT > 0 && ((KT / 2) & 1) == 1 && KT / 2 <= 32;
+			// ---- stage.  Short rows (K <= 62) are gathered SEVERAL per instruction: lane -> (row lane / PS, piece
+			// lane % PS) with PS = the tile row stride in pieces (P, or P + 1 when P is even: that lane is the padding
+			// and stays off), 12 rows at K=10, 5 at K=20 -- instead of one instruction with five active lanes per row.
+			constexpr bool kMultiRow = KT > 0 && ((KT / 2) | 1) <= 32;
 			if constexpr (kMultiRow) {
-				constexpr int PP = KT / 2, RPI = kWave / PP;   // pieces per row, rows per instruction
-				const int rr = lane / PP, piece = lane - rr * PP;
+				constexpr int PP = KT / 2, PS = PP | 1, RPI = kWave / PS;   // pieces, stride in pieces, rows per instruction
+				const int rr = lane / PS, piece = lane - rr * PS;
 				for (int n0 = 0; n0 < cnt; n0 += RPI) {
 					const int n = n0 + rr;
 					const int j = __shfl(my_idx, n < cnt ? n : 0);
 					const char *src = reinterpret_cast<const char *>(ybase) + (size_t) (unsigned) j * (size_t) (KT * 8) + 16 * piece;
-					if (rr < RPI && n < cnt)
+					if (rr < RPI && piece < PP && n < cnt)
 						__builtin_amdgcn_global_load_lds((mf_gvoid *) src, (mf_lvoid *) (tile + n0 * S), 16, 0, 0);
 				}
 			} else
