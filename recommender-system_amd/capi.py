@@ -297,6 +297,28 @@ def device_count():
     return hip().mf_backend_device_count()
 
 
+def file_sha256(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def kernel_source_hash():
+    """Hash (16 hex digits) of the kernel sources under csrc/: measurements kept in files (PMC traffic) are tied to
+    it, so a record is never quoted for kernels it was not measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.hip.h"))):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 # ------------------------------------------------------------------------------------ level 1
 def _problem(inst, iters=None):
     ent = (Entry * max(inst.nnz, 1))()

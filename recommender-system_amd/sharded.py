@@ -24,6 +24,27 @@ def shard_bounds(users, world, row_ptr=None, by_entries=True):
     return capi.partition_users(users, world, row_ptr if by_entries else None)
 
 
+def all_gather_arrays(arr, group=None):
+    """All-gather of one numpy array per rank (same dtype, different lengths along axis 0) with tensor collectives
+    only -- lengths first, then the byte images padded to the longest -- so nothing is pickled and, on RCCL, the
+    payload moves GPU to GPU (MPI_Gatherv, matFact-mpi.c:135).  Returns the list of arrays in rank order."""
+    arr = np.ascontiguousarray(arr)
+    world = dist.get_world_size(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    raw = torch.from_numpy(arr.reshape(-1).view(np.uint8).copy())
+    n = torch.tensor([raw.numel()], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(t.item()) for t in sizes]
+    width = max(max(sizes), 1)
+    mine = torch.zeros(width, dtype=torch.uint8, device=dev)
+    mine[:raw.numel()] = raw.to(dev)
+    parts = [torch.empty(width, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    tail = arr.shape[1:]
+    return [parts[g][:sizes[g]].cpu().numpy().view(arr.dtype).reshape((-1,) + tail) for g in range(world)]
+
+
 class ShardedFactorization:
     """Runs iterations of one shard and keeps the two R generations in torch tensors for the collective."""
 
@@ -81,8 +102,7 @@ class ShardedFactorization:
         mine = torch.from_numpy(np.ascontiguousarray(self.plan.recommend(), dtype=np.int32))
         if self.world == 1:
             return mine.numpy()
-        parts = [None] * self.world
-        dist.all_gather_object(parts, mine.numpy(), group=self.group)
+        parts = all_gather_arrays(mine.numpy(), group=self.group)
         out = np.empty(users_total, np.int32)
         for g in range(self.world):
             out[begin[g]:begin[g + 1]] = parts[g]
@@ -248,9 +268,14 @@ class GridFactorization:
         else:
             mine = None
         parts = [mine]
-        if world > 1:
+        if world > 1 and mine is not None:
+            # three tensor all-gathers (filter records, ||L[i]||, max ||R[j]||) instead of pickled objects
+            fs = all_gather_arrays(filt)
+            ns = all_gather_arrays(norm)
+            rs = all_gather_arrays(np.array([rmax], np.float64))
+            parts = [(fs[g], ns[g], float(rs[g][0])) for g in range(world)]
+        elif world > 1:
             parts = [None] * world
-            dist.all_gather_object(parts, mine)
         out = np.full(users_total, -1, np.int32)
         uncertain = {}                      # grid row -> local user ids that need the exact pass
         for gr in range(rows):
@@ -259,7 +284,10 @@ class GridFactorization:
                 uncertain[gr] = np.arange(n, dtype=np.int32)
                 continue
             blocks = [parts[gr * cols + gc] for gc in range(cols)]
-            ans, certain = certify_filters([b[0] for b in blocks], blocks[0][1], max(b[2] for b in blocks), margin)
+            # np.max propagates a NaN norm (Python's max would drop it unless it came first): thr is then NaN and
+            # nobody is certified
+            ans, certain = certify_filters([b[0] for b in blocks], blocks[0][1],
+                                           float(np.max(np.array([b[2] for b in blocks], np.float64))), margin)
             out[user_begin[gr]:user_begin[gr + 1]] = ans
             uncertain[gr] = np.flatnonzero(~certain).astype(np.int32)
         self.last_uncertain = int(sum(len(v) for v in uncertain.values()))
@@ -273,8 +301,7 @@ class GridFactorization:
             cand[f][cand[f] >= 0] += j0
         cparts = [cand]
         if world > 1:
-            cparts = [None] * world
-            dist.all_gather_object(cparts, cand)
+            cparts = all_gather_arrays(cand)
         for gr in range(rows):
             if len(uncertain[gr]) == 0:
                 continue

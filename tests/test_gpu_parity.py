@@ -247,21 +247,19 @@ def test_two_ranks_one_gpu_sharded_bench(capi):
     bench.py --check compares the sharded factors with a single-shard run: L and R within 1e-9 relative
     (only the 2-way re-association of the R sum differs; north-star tolerance 1e-5)."""
     import json
-    import socket
     import sys
     from conftest import ROOT
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+    # no launcher around it: bench.py starts its two ranks itself (child torch.distributed.run before any GPU call)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
            "--warmup", "1", "--config", "twin", "--backend", "gloo", "--check"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["rccl_ranks"] == 2 and out["collective_backend"] == "gloo"
+    assert out["ms_per_step_rank_max"] >= out["ms_per_step_rank_min"] > 0
+    assert out["recommend"]["recommended"] > 0 and out["check"]["recommend_differs"] <= 1
     assert out["check"]["L_max_rel"] < 1e-9 and out["check"]["R_max_rel"] < 1e-9, out["check"]
 
 
@@ -655,16 +653,10 @@ def test_four_ranks_one_gpu_grid_bench(capi):
     """bench.py --grid 2x2: four ranks share this box's GPU (gloo moves the CUDA tensors), each holding one tile
     with caller-owned L and R buffers; --check compares with a single-shard run on the same GPU."""
     import json
-    import socket
     import sys
     from conftest import ROOT
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3",
-           "--warmup", "1", "--config", "twin", "--backend", "gloo", "--grid", "2x2", "--check", "--recommend"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3",
+           "--warmup", "1", "--config", "twin", "--backend", "gloo", "--grid", "2x2", "--check"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])

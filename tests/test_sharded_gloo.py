@@ -309,3 +309,69 @@ def test_filter_certification_over_item_blocks():
     assert certain[3] and ans[3] == -1
     assert not certain[5] and not certain[6] and not certain[7] and not certain[8] and not certain[9]
     assert certain.sum() > users * 0.9
+
+
+def test_certify_filters_nan_rmax_in_a_later_block_certifies_nobody():
+    """the largest max||R[j]|| of a grid row must PROPAGATE a NaN wherever it sits (Python's max drops a
+    NaN unless it comes first); with a NaN threshold nobody who has a candidate is certified."""
+    import recommender_system_amd as rs
+    sh = __import__("importlib").import_module("recommender_system_amd.sharded")
+    users = 5
+    filters = []
+    for b in range(3):
+        f = np.zeros(users, rs.capi.FILTER_DTYPE)
+        f["best"], f["second"], f["arg"] = 10.0 * (b + 1), 0.0, 7 * b
+        filters.append(f)
+    rmaxes = [1.0, float("nan"), 2.0]
+    assert max(rmaxes) == 2.0                                    # the trap
+    rmax = float(np.max(np.array(rmaxes)))
+    assert rmax != rmax
+    ans, certain = sh.certify_filters(filters, np.ones(users), rmax, 1e-9)
+    assert not certain.any()
+    ans, certain = sh.certify_filters(filters, np.ones(users), 2.0, 1e-9)
+    assert certain.all() and (ans == 14).all()
+
+
+def _gather_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import recommender_system_amd as rs
+    mine = np.zeros(3 * rank, rs.capi.CANDIDATE_DTYPE)          # rank 0 contributes an EMPTY array
+    mine["best"] = np.arange(3 * rank) + 100 * rank
+    mine["score"] = rank + 0.5
+    parts = rs.sharded.all_gather_arrays(mine)
+    mat = rs.sharded.all_gather_arrays(np.full((rank + 1, 4), float(rank)))
+    ok = all(p.dtype == rs.capi.CANDIDATE_DTYPE and len(p) == 3 * g and (p["score"] == g + 0.5).all() and
+             (p["best"] == np.arange(3 * g) + 100 * g).all() for g, p in enumerate(parts))
+    ok = ok and all(m.shape == (g + 1, 4) and (m == g).all() for g, m in enumerate(mat))
+    if rank == world - 1:
+        np.save(out_path, np.array([ok]))
+    dist.destroy_process_group()
+
+
+def test_all_gather_arrays_ragged_structured(tmp_path):
+    """The tensor-collective replacement of all_gather_object: ragged lengths (one rank empty), record dtypes and
+    2-D arrays come back in rank order."""
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_gather_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    assert bool(np.load(out)[0])
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks itself (child torch.distributed.run,
+    before any GPU call).  Without a GPU here each rank stops at the no-device check -- the message names the rank
+    and the world size, which proves the launcher ran; on the GPU box the same command is run by the gpu tests."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1",
+                        "--warmup", "0", "--config", "twin", "--no-cpu-baseline"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    import recommender_system_amd as rs
+    if rs.capi.device_count() > 0:
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = __import__("json").loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2
+    else:
+        assert r.returncode != 0
+        assert "rank 0/2 needs an MI355X" in r.stderr and "rank 1/2 needs an MI355X" in r.stderr, r.stderr[-2000:]
