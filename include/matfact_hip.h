@@ -29,7 +29,10 @@
 extern "C" {
 #endif
 
-#define MATFACT_HIP_ABI_VERSION 2   /* 2: mf_shard.users_ext, seeded user sweep, scored recommend (2-D tiles) */
+#define MATFACT_HIP_ABI_VERSION 3   /* 2: mf_shard.users_ext, seeded user sweep, scored recommend (2-D tiles)
+                                       3: mf_backend_multi_last_timing, MF_MULTI_REDUCE=peer|rccl; the reserved
+                                          MF_PLAN_RELAXED_ORDER flag is gone (never implemented: an atomic sum is
+                                          order-nondeterministic and slower than the owner-computes gather) */
 
 /* == non_zero_entry, datatypes.h:10-15: the (user, item, rating) triple, 16 bytes, array-of-structs */
 typedef struct mf_entry {
@@ -83,11 +86,19 @@ int mf_backend_run(const mf_problem *p, double *L, double *R, int32_t *best, int
 int mf_backend_run_top1(const mf_problem *p, const double *L0, const double *R0, int32_t *best, int device);
 
 /* The same on several GPUs of ONE process: users are cut into ndev contiguous blocks balanced by entry count,
- * L blocks are private, R is replicated and summed after every item sweep by a peer-to-peer reduce over xGMI
- * (the decomposition of matFact-mpi.c:155-214 with the 8x1 grid of mpiutil.c:54-88).  devices[] lists HIP
- * ordinals; an ordinal may repeat (several shards on one GPU -- how the path is tested on a one-GPU box).
- * Peer access between distinct devices is required (MF_ERR_UNSUPPORTED otherwise).  ndev <= 16. */
+ * L blocks are private, R is replicated and summed after every item sweep (the decomposition of
+ * matFact-mpi.c:155-214 with the 8x1 grid of mpiutil.c:54-88; items are cut instead when items > users).  The sum
+ * is the MPI_Iallreduce of matFact-mpi.c:207-208: environment MF_MULTI_REDUCE=peer (default) uses a hand-written
+ * peer-to-peer reduce over xGMI (needs peer access between distinct devices, MF_ERR_UNSUPPORTED otherwise),
+ * MF_MULTI_REDUCE=rccl uses ncclAllReduce(ncclDouble, ncclSum) on a communicator made by ncclCommInitAll (needs
+ * distinct devices).  The reduce runs on its own stream beside the user sweep.  devices[] lists HIP ordinals; with
+ * the peer reducer an ordinal may repeat (several shards on one GPU -- how the path is tested on a one-GPU box).
+ * ndev <= 16. */
 int mf_backend_run_multi(const mf_problem *p, double *L, double *R, int32_t *best, const int *devices, int ndev);
+/* Host wall-clock of the last mf_backend_run_multi of this process: set-up (bucketing + plan builds + uploads),
+ * iterations, recommendations; info[0] = shards, info[1] = reducer (0 peer, 1 rccl), info[2] = 1 when the shards
+ * were slices of the caller's array (input sorted by the cut key: no bucketing pass).  Any pointer may be NULL. */
+int mf_backend_multi_last_timing(double *setup_s, double *iterate_s, double *recommend_s, int *info);
 
 /* ------------------------------------------------------------------------------------------ LEVEL 2 */
 
@@ -119,8 +130,7 @@ typedef struct mf_shard {
  * matFact-mpi.c:193), exactly as user ids are relative to user_begin inside the plan.  Item indices that
  * mf_plan_recommend* return are then block-relative too. */
 
-#define MF_PLAN_DEFAULT 0
-#define MF_PLAN_RELAXED_ORDER 1   /* reserved: allow re-associated sums (tolerance mode) */
+#define MF_PLAN_DEFAULT 0   /* no flag bits are defined: every sum is formed in the serial order */
 
 int mf_plan_create(mf_plan **out, const mf_shard *shard);
 void mf_plan_destroy(mf_plan *plan);

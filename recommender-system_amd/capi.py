@@ -27,6 +27,7 @@ MF_ERR_ARGUMENT, MF_ERR_NO_DEVICE, MF_ERR_HIP, MF_ERR_NO_MEMORY, MF_ERR_UNSUPPOR
 HIP_SYMBOLS = [
     "mf_backend_strerror", "mf_backend_last_hip_error", "mf_backend_abi_version", "mf_backend_device_count",
     "mf_backend_factorize", "mf_backend_recommend", "mf_backend_run", "mf_backend_run_multi", "mf_backend_run_top1",
+    "mf_backend_multi_last_timing",
     "mf_plan_create", "mf_plan_destroy", "mf_plan_set_stream", "mf_plan_upload_factors",
     "mf_plan_download_factors", "mf_plan_iterate", "mf_plan_sweep_items", "mf_plan_sweep_users",
     "mf_plan_items_next", "mf_plan_items_current", "mf_plan_flip", "mf_plan_recommend", "mf_plan_recommend_info",
@@ -103,6 +104,8 @@ def hip():
         lib.mf_backend_last_hip_error.restype = C.c_char_p
         lib.mf_backend_run.argtypes = [C.POINTER(Problem), _f64p, _f64p, _i32p, C.c_int]
         lib.mf_backend_run_multi.argtypes = [C.POINTER(Problem), _f64p, _f64p, _i32p, _i32p, C.c_int]
+        lib.mf_backend_multi_last_timing.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                                     C.POINTER(C.c_double), C.POINTER(C.c_int * 3)]
         lib.mf_backend_run_top1.argtypes = [C.POINTER(Problem), _f64p, _f64p, _i32p, C.c_int]
         lib.mf_backend_factorize.argtypes = [C.POINTER(Problem), _f64p, _f64p, C.c_int]
         lib.mf_backend_recommend.argtypes = [C.POINTER(Problem), _f64p, _f64p, _i32p, C.c_int]
@@ -346,6 +349,16 @@ def backend_run_multi(inst, L, R, devices, iters=None):
     dev = np.ascontiguousarray(devices, np.int32)
     _check(hip().mf_backend_run_multi(C.byref(p), L, R, best, dev, len(dev)), "mf_backend_run_multi")
     return best
+
+
+def multi_last_timing():
+    """Host wall-clock of the last backend_run_multi: dict(setup_s, iterate_s, recommend_s, shards, reducer, sliced)."""
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    info = (C.c_int * 3)()
+    _check(hip().mf_backend_multi_last_timing(C.byref(a), C.byref(b), C.byref(c), C.byref(info)),
+           "mf_backend_multi_last_timing")
+    return {"setup_s": a.value, "iterate_s": b.value, "recommend_s": c.value, "shards": info[0],
+            "reducer": "rccl" if info[1] else "peer", "sliced": bool(info[2])}
 
 
 def backend_run_top1(inst, L0, R0, iters=None, device=0):

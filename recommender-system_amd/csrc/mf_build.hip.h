@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256) split_entries_kernel(const mf_entry *__re
 	val[n] = x.value;
 }
 
-int build_on_device(mf_plan *p, const mf_shard *s, const mf_entry *aos, std::vector<int> &csr_ptr_host,
+int build_on_device(mf_plan *p, const mf_shard *s, const mf_entry *aos, bool swap, std::vector<int> &csr_ptr_host,
                     std::vector<int> &csc_ptr_host)
 {
 	const int64_t nnz = s->nnz;
@@ -160,7 +160,8 @@ int build_on_device(mf_plan *p, const mf_shard *s, const mf_entry *aos, std::vec
 		mf_entry *d_aos = nullptr;
 		if ((rc = tmp.get(&d_aos, nz)) != MF_OK) return rc;
 		MF_HIP(hipMemcpyAsync(d_aos, aos, nz * sizeof(mf_entry), hipMemcpyHostToDevice, st));
-		hipLaunchKernelGGL(split_entries_kernel, dim3(grid), dim3(256), 0, st, d_aos, nnz, d_row, d_col, p->csr_val);
+		hipLaunchKernelGGL(split_entries_kernel, dim3(grid), dim3(256), 0, st, d_aos, nnz, swap ? d_col : d_row,
+		                   swap ? d_row : d_col, p->csr_val);
 	} else {
 		MF_HIP(hipMemcpyAsync(d_row, s->row, nz * sizeof(int), hipMemcpyHostToDevice, st));
 		MF_HIP(hipMemcpyAsync(d_col, s->col, nz * sizeof(int), hipMemcpyHostToDevice, st));
@@ -227,7 +228,8 @@ int build_on_device(mf_plan *p, const mf_shard *s, const mf_entry *aos, std::vec
 
 // CSR over the shard's users and CSC over the items, on the device (default) or bucketed on the host
 // (MF_BUILD=host, kept for A/B tests); rptr / cptr return the two row-pointer arrays for the schedule decisions.
-int build_sparse(mf_plan *p, const mf_shard *s_in, const mf_entry *aos, std::vector<int> &rptr, std::vector<int> &cptr)
+int build_sparse(mf_plan *p, const mf_shard *s_in, const mf_entry *aos, bool swap, std::vector<int> &rptr,
+                 std::vector<int> &cptr)
 {
 	const char *where = getenv("MF_BUILD");
 	if (where && strcmp(where, "host") == 0) {
@@ -244,8 +246,8 @@ int build_sparse(mf_plan *p, const mf_shard *s_in, const mf_entry *aos, std::vec
 				return MF_ERR_NO_MEMORY;
 			}
 			for (int64_t n = 0; n < sh.nnz; ++n) {
-				hrow[(size_t) n] = aos[n].row;
-				hcol[(size_t) n] = aos[n].col;
+				hrow[(size_t) n] = swap ? aos[n].col : aos[n].row;
+				hcol[(size_t) n] = swap ? aos[n].row : aos[n].col;
 				hval[(size_t) n] = aos[n].value;
 			}
 			sh.row = hrow.data();
@@ -287,7 +289,7 @@ int build_sparse(mf_plan *p, const mf_shard *s_in, const mf_entry *aos, std::vec
 			MF_TRY_HIP(hipMemcpy(p->csc_val, val.data(), nz * sizeof(double), hipMemcpyHostToDevice));
 		}
 	} else {
-		MF_TRY(build_on_device(p, s_in, aos, rptr, cptr));
+		MF_TRY(build_on_device(p, s_in, aos, swap, rptr, cptr));
 	}
 	return MF_OK;
 }

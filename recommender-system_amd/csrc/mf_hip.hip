@@ -56,7 +56,8 @@ int mf_backend_device_count(void)
 
 // `aos` (optional): the entries as the reference's array of (row, col, value) structs; they are then uploaded as they
 // are and split into the three arrays on the device (the level-1 entry points: no host-side copy of 1e8 entries).
-static int plan_create_impl(mf_plan **out, const mf_shard *s, const mf_entry *aos)
+// `swap`: read the structs with row and col exchanged (the item-cut form of mf_backend_run_multi).
+static int plan_create_impl(mf_plan **out, const mf_shard *s, const mf_entry *aos, bool swap = false)
 {
 	if (!out) return MF_ERR_ARGUMENT;
 	*out = nullptr;
@@ -112,7 +113,7 @@ static int plan_create_impl(mf_plan **out, const mf_shard *s, const mf_entry *ao
 	} while (0)
 	{
 		std::vector<int> rptr, cptr;
-		MF_TRY(build_sparse(p, s, aos, rptr, cptr));
+		MF_TRY(build_sparse(p, s, aos, swap, rptr, cptr));
 		MF_TRY(plan_row_schedule(p, rptr, cptr));
 	}
 
@@ -702,8 +703,6 @@ int mf_backend_run_top1(const mf_problem *pr, const double *L0, const double *R0
 	return rc;
 }
 
-#include "mf_multi.hip.h"
-
 int mf_backend_factorize(const mf_problem *pr, double *L, double *R, int device)
 {
 	return mf_backend_run(pr, L, R, nullptr, device);
@@ -722,3 +721,5 @@ int mf_backend_recommend(const mf_problem *pr, const double *L, const double *R,
 }
 
 }  // extern "C"
+
+#include "mf_multi.hip.h"

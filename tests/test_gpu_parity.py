@@ -770,3 +770,110 @@ def test_run_top1_gives_the_list_of_the_full_run(capi, orc):
     assert np.array_equal(Lc, L0) and np.array_equal(Rc, R0)
     Lo, Ro, bo = orc.run(orc.Instance(**d))
     assert np.array_equal(best, bo)
+
+
+# ------------------------------------------------------------------ BASELINE.json configs at their own sizes
+def _spot_check_one_iteration(orc, U, I, K, alpha, row, col, val, L0, R0, L1, R1, n_users, n_items, seed=0):
+    """Exact check of sampled rows after ONE iteration: a row of L_new depends only on that user's entries and the
+    old factors, a row of R_new only on that item's entries -- the oracle's block update (matFact-mpi.c:185-205 with
+    one rank), fed the filtered entries in file order, reproduces those rows bit for bit."""
+    rng = np.random.default_rng(seed)
+    users = np.sort(rng.choice(U, min(n_users, U), replace=False))
+    sel = np.isin(row, users)
+    Lo, _ = orc.shard_step(0, U, I, K, row[sel], col[sel], val[sel], alpha, L0, R0, True)
+    assert np.array_equal(L1[users], Lo[users]), "sampled user rows differ from the oracle"
+    items = np.sort(rng.choice(I, min(n_items, I), replace=False))
+    sel = np.isin(col, items)
+    _, Ro = orc.shard_step(0, U, I, K, row[sel], col[sel], val[sel], alpha, L0, R0, True)
+    assert np.array_equal(R1[items], Ro[items]), "sampled item rows differ from the oracle"
+    return users
+
+
+def _check_recommend_rows(orc, best, users, row, col, L, R, U, I):
+    ptr = np.concatenate([[0], np.cumsum(np.bincount(row, minlength=U))])
+    for uu in users:
+        b = orc.predict_row(L[uu], R)
+        b[col[ptr[uu]:ptr[uu + 1]]] = -np.inf          # rated items never win; scores here are finite
+        exp = int(np.argmax(b))                          # first maximum == strict '>' scanning j ascending
+        assert best[uu] == exp, (uu, best[uu], exp)
+
+
+@pytest.mark.parametrize("skew", [False, True])
+def test_cfg3_ml1m_shaped_full_size_bit_exact(capi, orc, skew):
+    """BASELINE.json configs[2] (instML1M.in is absent from the reference checkout: the ML1M-shaped synthetic
+    stand-in of bench.py, 6040 x 3952, K=100, ~1e6 entries), uniform and power-law, at FULL size: two iterations
+    bit-exact against the serial oracle, recommendations identical."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    cfg = bench.CONFIGS["cfg3"]
+    U, I, K = cfg["users"], cfg["items"], cfg["feats"]
+    row, col, val = capi.synth_block(cfg["seed"], U, I, cfg["min_row"], cfg["max_row"])
+    if skew:
+        row, col, val = bench.skewed_instance(cfg["seed"], U, I, int(row.shape[0]))
+    assert 8e5 < row.shape[0] < 1.2e6
+    d = dict(iters=2, alpha=cfg["alpha"], feats=K, users=U, items=I, row=row, col=col, val=val)
+    L, R = capi.init_factors(U, I, K)
+    best = capi.backend_run(_inst(capi, d), L, R)
+    Lo, Ro, bo = _oracle_run(orc, d)
+    assert np.array_equal(L, Lo) and np.array_equal(R, Ro)
+    assert np.array_equal(best, bo)
+
+
+def test_cfg5_shape_scaled_twin_spot_checks(capi, orc):
+    """BASELINE.json configs[4]'s shape (K=256, rows of 250..750 entries, seed 0xC0FFEE+5) at 2e4 x 2e4 (~1e7
+    entries): sweep_dma_kernel<256,2> through long rows, sampled rows exact against the oracle, determinism,
+    and the K=256 recommendation over 157 user blocks checked exactly on sampled users."""
+    U, I, K, alpha = 20_000, 20_000, 256, 1e-5
+    row, col, val = capi.synth_block(0xC0FFEE + 5, U, I, 250, 750)
+    assert 0.9e7 < row.shape[0] < 1.1e7
+    L0, R0 = capi.init_factors(U, I, K)
+    plan = capi.Plan(U, I, K, alpha, row, col, val)
+    assert "KT=256" in plan.describe(), plan.describe()
+    plan.upload(L0, R0)
+    plan.iterate(1)
+    L1, R1 = plan.download()
+    users = _spot_check_one_iteration(orc, U, I, K, alpha, row, col, val, L0, R0, L1, R1, 300, 40, seed=5)
+    plan.upload(L0, R0)
+    plan.iterate(1)
+    L1b, R1b = plan.download()
+    assert np.array_equal(L1, L1b) and np.array_equal(R1, R1b)
+    best = plan.recommend()
+    assert plan.recommend_info() >= 0                    # the matrix-core form ran
+    _check_recommend_rows(orc, best, users[:25], row, col, L1, R1, U, I)
+    plan.close()
+
+
+def test_cfg4_full_size_spot_checks_and_properties(capi, orc):
+    """BASELINE.json configs[3] -- the bench workload itself, 1e6 x 1e5, K=100, ~1e8 entries -- at FULL size:
+    300 users / 40 items of the first iteration exact against the oracle, bit-reproducible, alpha = 0 is the
+    identity, sampled recommendations exact."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    cfg = bench.CONFIGS["cfg4"]
+    U, I, K, alpha = cfg["users"], cfg["items"], cfg["feats"], cfg["alpha"]
+    row, col, val = capi.synth_block(cfg["seed"], U, I, cfg["min_row"], cfg["max_row"])
+    assert row.shape[0] > 99_000_000
+    L0, R0 = capi.init_factors(U, I, K)
+    plan = capi.Plan(U, I, K, alpha, row, col, val)
+    plan.upload(L0, R0)
+    plan.iterate(1)
+    L1, R1 = plan.download()
+    users = _spot_check_one_iteration(orc, U, I, K, alpha, row, col, val, L0, R0, L1, R1, 300, 40, seed=4)
+    best = plan.recommend()
+    _check_recommend_rows(orc, best, users[:12], row, col, L1, R1, U, I)
+    plan.upload(L0, R0)
+    plan.iterate(1)
+    L1b, R1b = plan.download()
+    assert np.array_equal(L1, L1b) and np.array_equal(R1, R1b)
+    del L1b, R1b
+    plan.close()
+    plan0 = capi.Plan(U, I, K, 0.0, row, col, val)
+    plan0.upload(L0, R0)
+    plan0.iterate(2)
+    Lz, Rz = plan0.download()
+    plan0.close()
+    assert np.array_equal(Lz, L0) and np.array_equal(Rz, R0)
