@@ -169,6 +169,7 @@ void mf_plan_destroy(mf_plan *p)
 		(void) hipFree(p->Lbuf[1]);
 	}
 	(void) hipFree(p->cand_dev);
+	(void) hipFree(p->cand_pack);
 	(void) hipFree(p->filt_dev);
 	if (!p->r_external) {
 		(void) hipFree(p->Rbuf[0]);
@@ -544,15 +545,16 @@ int mf_plan_recommend_scored_users(mf_plan *p, const int32_t *users, int32_t n, 
 	ex.cand = p->cand_dev;   // written at the user's own index
 	hipLaunchKernelGGL(mf::recommend_kernel, dim3((n + mf::kRT - 1) / mf::kRT), dim3(256), 0, p->stream, ex);
 	MF_HIP(hipGetLastError());
-	std::vector<mf_candidate> all;
-	try {
-		all.resize((size_t) p->uc);
-	} catch (const std::bad_alloc &) {
-		return MF_ERR_NO_MEMORY;
+	// only the n requested records travel: packed on the device in list order
+	if (!p->cand_pack) {
+		const int rc = dev_alloc(&p->cand_pack, (size_t) p->uc);
+		if (rc != MF_OK) return rc;
 	}
-	MF_HIP(hipMemcpyAsync(all.data(), p->cand_dev, (size_t) p->uc * sizeof(mf_candidate), hipMemcpyDeviceToHost, p->stream));
+	hipLaunchKernelGGL(mf::pack_candidates_kernel, dim3((n + 255) / 256), dim3(256), 0, p->stream, p->cand_dev, p->ulist,
+	                   n, p->cand_pack);
+	MF_HIP(hipGetLastError());
+	MF_HIP(hipMemcpyAsync(out, p->cand_pack, (size_t) n * sizeof(mf_candidate), hipMemcpyDeviceToHost, p->stream));
 	MF_HIP(hipStreamSynchronize(p->stream));
-	for (int32_t t = 0; t < n; ++t) out[t] = all[(size_t) users[t]];
 	return MF_OK;
 }
 

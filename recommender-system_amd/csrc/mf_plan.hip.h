@@ -114,6 +114,7 @@ struct mf_plan {
 	bool l_external = false;
 	bool join_pending = false;          // ordered sums of the last item sweep still run on the side stream
 	mf_candidate *cand_dev = nullptr;   // recommend_scored output, allocated on first use
+	mf_candidate *cand_pack = nullptr;  // the listed users' records in list order (recommend_scored_users)
 	mf_filter *filt_dev = nullptr;      // recommend_filter output, allocated on first use
 	int cur = 0;            // generation index of the current factors
 	bool have_factors = false;

@@ -173,6 +173,15 @@ __global__ void __launch_bounds__(256) recommend_kernel(RecArgs a)
 }
 
 
+// out[t] = cand[ulist[t]]: the records of the listed users in list order (only those are copied to the host)
+__global__ void __launch_bounds__(256) pack_candidates_kernel(const mf_candidate *__restrict__ cand,
+                                                              const int *__restrict__ ulist, int n,
+                                                              mf_candidate *__restrict__ out)
+{
+	const int t = blockIdx.x * 256 + threadIdx.x;
+	if (t < n) out[t] = cand[ulist[t]];
+}
+
 // Dense B = L R^T (mat2d_prod, mat2d.c:100-113) for the debug dump of small instances: one thread per
 // (i, j), sequential k from 0.0, separate multiply and add -- every element equals the reference's B[i][j].
 __global__ void __launch_bounds__(256) predict_kernel(const double *__restrict__ L, const double *__restrict__ R,

@@ -877,3 +877,79 @@ def test_cfg4_full_size_spot_checks_and_properties(capi, orc):
     Lz, Rz = plan0.download()
     plan0.close()
     assert np.array_equal(Lz, L0) and np.array_equal(Rz, R0)
+
+
+# ------------------------------------------------------------------ mf_backend_run_multi: reducers, bucketing, set-up cost
+def test_multi_rccl_reducer_single_rank_is_the_single_gpu_run(capi, orc, monkeypatch):
+    """MF_MULTI_REDUCE=rccl through the C host path: ncclCommInitAll + ncclAllReduce(ncclDouble, ncclSum) on the
+    reduce stream (matFact-mpi.c:207-208).  A one-GPU box can only host ONE rank (RCCL refuses two ranks on one
+    device), so MF_MULTI_FORCE=1 takes the sharded path with a single shard: the all-reduce over one rank is the
+    identity and the result must equal the serial run bit for bit.  Repeated ordinals are refused for RCCL."""
+    d = random_instance(92, 120, 90, 30, density=0.25, iters=8, alpha=0.002, empty_rows=(3,), full_rows=(8,))
+    Lo, Ro, bo = _oracle_run(orc, d)
+    monkeypatch.setenv("MF_MULTI_FORCE", "1")
+    for reducer in ("rccl", "peer"):
+        monkeypatch.setenv("MF_MULTI_REDUCE", reducer)
+        L, R = capi.init_factors(120, 90, 30)
+        best = capi.backend_run_multi(_inst(capi, d), L, R, [0])
+        t = capi.multi_last_timing()
+        assert t["reducer"] == reducer and t["shards"] == 1 and t["sliced"]
+        assert np.array_equal(L, Lo) and np.array_equal(R, Ro) and np.array_equal(best, bo), reducer
+    monkeypatch.setenv("MF_MULTI_REDUCE", "rccl")
+    with pytest.raises(capi.HipBackendError) as e:
+        capi.backend_run_multi(_inst(capi, d), L, R, [0, 0])
+    assert e.value.status == capi.MF_ERR_UNSUPPORTED
+
+
+def test_multi_unsorted_input_takes_the_bucketing_pass(capi, orc):
+    """Entries in a random file order: the shards can no longer be slices of the caller's array, one stable scatter
+    pass buckets them by owner; factors as for the sorted file up to re-association, in both cut directions."""
+    for (u, i) in ((150, 60), (40, 300)):           # users cut / items cut
+        d = random_instance(93 + u, u, i, 20, density=0.3, iters=6, alpha=0.002)
+        inst = orc.Instance(**d)
+        Lo, Ro = orc.init_factors(u, i, 20)
+        rng = np.random.default_rng(3)
+        perm = rng.permutation(len(d["row"]))
+        dp = dict(d, row=np.ascontiguousarray(d["row"][perm]), col=np.ascontiguousarray(d["col"][perm]),
+                  val=np.ascontiguousarray(d["val"][perm]))
+        orc.factorize(orc.Instance(**dp), Lo, Ro)    # the serial program on the permuted file
+        L, R = capi.init_factors(u, i, 20)
+        capi.backend_run_multi(_inst(capi, dp), L, R, [0, 0, 0])
+        t = capi.multi_last_timing()
+        assert not t["sliced"] and t["shards"] == 3
+        assert np.allclose(L, Lo, rtol=1e-9, atol=1e-13) and np.allclose(R, Ro, rtol=1e-9, atol=1e-13), (u, i)
+        # the sorted file, items cut: sorted by row but not by column -> bucketing for the factorisation, slices again
+        # for the user-block recommendation plans
+        Ls, Rs = capi.init_factors(u, i, 20)
+        best = capi.backend_run_multi(_inst(capi, d), Ls, Rs, [0, 0])
+        assert capi.multi_last_timing()["sliced"] == (u >= i)
+        L1, R1 = orc.init_factors(u, i, 20)
+        orc.factorize(inst, L1, R1)
+        assert np.array_equal(best, orc.recommend(inst, L1, R1))
+
+
+def test_multi_setup_does_not_grow_with_the_shard_count(capi, monkeypatch):
+    """set-up was O(shards * nnz) on the host.  cfg4's shape at 1/5 scale (2e5 x 2e4, ~2e7 entries):
+    set-up (bucketing + plan builds + uploads) for 8 shards must not be slower than for 1, the 8-shard factors must
+    agree with the 1-shard ones to re-association accuracy and the recommendations must be identical."""
+    U, I, K = 200_000, 20_000, 100
+    row, col, val = capi.synth_block(0xC0FFEE + 4, U, I, 50, 150)
+    inst = capi.Instance(2, 1e-4, K, U, I, row, col, val)
+    p, keep = capi._problem(inst)
+    dev1, dev8 = np.zeros(1, np.int32), np.zeros(8, np.int32)
+    monkeypatch.setenv("MF_MULTI_FORCE", "1")
+    res = {}
+    for name, dev in (("warm", dev1), ("one", dev1), ("eight", dev8)):
+        L, R = capi.init_factors(U, I, K)
+        best = np.empty(U, np.int32)
+        import ctypes as C
+        capi._check(capi.hip().mf_backend_run_multi(C.byref(p), L, R, best, dev, len(dev)), "mf_backend_run_multi")
+        res[name] = (L, R, best, capi.multi_last_timing())
+    t1, t8 = res["one"][3], res["eight"][3]
+    assert t1["sliced"] and t8["sliced"] and t8["shards"] == 8
+    assert t8["setup_s"] <= 1.25 * t1["setup_s"] + 0.05, (t1, t8)
+    assert np.allclose(res["eight"][0], res["one"][0], rtol=1e-9, atol=1e-13)
+    assert np.allclose(res["eight"][1], res["one"][1], rtol=1e-9, atol=1e-13)
+    assert (res["eight"][2] != res["one"][2]).sum() <= 2    # a near-tie may resolve differently after re-association
+    print("multi set-up 1 shard %.3f s, 8 shards %.3f s; recommend %.3f / %.3f s" % (
+        t1["setup_s"], t8["setup_s"], t1["recommend_s"], t8["recommend_s"]))
