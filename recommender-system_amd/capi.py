@@ -506,6 +506,6 @@ class Plan:
         return {"item_launches": il.value, "item_ms": ims.value, "user_launches": ul.value, "user_ms": ums.value}
 
     def describe(self):
-        buf = C.create_string_buffer(256)
-        _check(hip().mf_plan_describe(self._h, buf, 256), "mf_plan_describe")
+        buf = C.create_string_buffer(512)
+        _check(hip().mf_plan_describe(self._h, buf, 512), "mf_plan_describe")
         return buf.value.decode()

@@ -22,8 +22,9 @@ int dev_alloc(T **out, size_t count)
 // stable counting sort of the entries by `key` into (ptr, idx, val)
 void bucket(int64_t nnz, int nkeys, const int32_t *key, int32_t key_off, const int32_t *other,
             int32_t other_off, const double *val, std::vector<int> &ptr, std::vector<int> &idx,
-            std::vector<double> &v)
+            std::vector<double> &v, std::vector<int> *pos_out = nullptr)
 {
+	if (pos_out) pos_out->resize((size_t) nnz);
 	ptr.assign((size_t) nkeys + 1, 0);
 	for (int64_t n = 0; n < nnz; ++n) ptr[(size_t) (key[n] - key_off) + 1]++;
 	for (int k = 0; k < nkeys; ++k) ptr[(size_t) k + 1] += ptr[k];
@@ -34,6 +35,7 @@ void bucket(int64_t nnz, int nkeys, const int32_t *key, int32_t key_off, const i
 		const int pos = fill[(size_t) (key[n] - key_off)]++;
 		idx[(size_t) pos] = other[n] - other_off;
 		v[(size_t) pos] = val[n];
+		if (pos_out) (*pos_out)[(size_t) n] = pos;
 	}
 }
 
@@ -90,6 +92,24 @@ __global__ void __launch_bounds__(256) copy_keys_kernel(const int *__restrict__ 
 	perm[n] = (unsigned) n;
 }
 
+// inverse of a permutation: inv[perm[q]] = q
+__global__ void __launch_bounds__(256) invert_perm_kernel(const unsigned *__restrict__ perm, int64_t nnz,
+                                                          int *__restrict__ inv)
+{
+	const int64_t q = (int64_t) blockIdx.x * 256 + threadIdx.x;
+	if (q < nnz) inv[perm[q]] = (int) q;
+}
+
+// map[file2csr ? file2csr[perm_csc[q]] : perm_csc[q]] = q: CSR position -> CSC position of the same entry
+__global__ void __launch_bounds__(256) csr2csc_kernel(const unsigned *__restrict__ perm_csc, int64_t nnz,
+                                                      const int *__restrict__ file2csr, int *__restrict__ map)
+{
+	const int64_t q = (int64_t) blockIdx.x * 256 + threadIdx.x;
+	if (q >= nnz) return;
+	const unsigned f = perm_csc[q];
+	map[file2csr ? file2csr[f] : (int) f] = (int) q;
+}
+
 int bits_for(int nkeys)
 {
 	int b = 1;
@@ -143,7 +163,7 @@ int build_on_device(mf_plan *p, const mf_shard *s, const mf_entry *aos, bool swa
 		return MF_OK;
 	}
 	DevTmp tmp;
-	int *d_row = nullptr, *d_col = nullptr, *d_flags = nullptr;
+	int *d_row = nullptr, *d_col = nullptr, *d_flags = nullptr, *file2csr = nullptr;
 	unsigned *key_in = nullptr, *key_out = nullptr, *perm_in = nullptr, *perm_out = nullptr;
 	int rc;
 	if ((rc = tmp.get(&d_row, nz)) != MF_OK || (rc = tmp.get(&d_col, nz)) != MF_OK ||
@@ -200,6 +220,10 @@ int build_on_device(mf_plan *p, const mf_shard *s, const mf_entry *aos, bool swa
 		                   p->csr_idx, p->csr_val);
 		hipLaunchKernelGGL(ptr_kernel, dim3((unsigned) ((p->uc + 256) / 256)), dim3(256), 0, st, key_out, nnz, p->uc,
 		                   p->csr_ptr);
+		if (p->want_map) {
+			if ((rc = tmp.get(&file2csr, nz)) != MF_OK) return rc;
+			hipLaunchKernelGGL(invert_perm_kernel, dim3(grid), dim3(256), 0, st, perm_out, nnz, file2csr);
+		}
 	}
 	// CSC: stable sort of the file order by column
 	hipLaunchKernelGGL(copy_keys_kernel, dim3(grid), dim3(256), 0, st, d_col, nnz, key_in, perm_in);
@@ -218,6 +242,10 @@ int build_on_device(mf_plan *p, const mf_shard *s, const mf_entry *aos, bool swa
 	}
 	hipLaunchKernelGGL(ptr_kernel, dim3((unsigned) ((p->items + 256) / 256)), dim3(256), 0, st, key_out, nnz, p->items,
 	                   p->csc_ptr);
+	if (p->want_map) {
+		MF_HIP(dev_alloc(&p->csr2csc, nz + 64) == MF_OK ? hipSuccess : hipErrorOutOfMemory);
+		hipLaunchKernelGGL(csr2csc_kernel, dim3(grid), dim3(256), 0, st, perm_out, nnz, file2csr, p->csr2csc);
+	}
 	MF_HIP(hipGetLastError());
 	MF_HIP(hipMemcpyAsync(csr_ptr_host.data(), p->csr_ptr, ((size_t) p->uc + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
 	MF_HIP(hipMemcpyAsync(csc_ptr_host.data(), p->csc_ptr, ((size_t) p->items + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -259,11 +287,11 @@ int build_sparse(mf_plan *p, const mf_shard *s_in, const mf_entry *aos, bool swa
 			if (s->row[n] < s->user_begin || s->row[n] >= s->user_begin + s->user_count || s->col[n] < 0 ||
 			    s->col[n] >= s->items)
 				return MF_ERR_ARGUMENT;
-		std::vector<int> idx;
+		std::vector<int> idx, pos_r, pos_c;
 		std::vector<double> val;
 		const size_t nz = (size_t) s->nnz;
 		try {
-			bucket(s->nnz, p->uc, s->row, p->u0, s->col, 0, s->val, rptr, idx, val);
+			bucket(s->nnz, p->uc, s->row, p->u0, s->col, 0, s->val, rptr, idx, val, p->want_map ? &pos_r : nullptr);
 		} catch (const std::bad_alloc &) {
 			return MF_ERR_NO_MEMORY;
 		}
@@ -276,7 +304,7 @@ int build_sparse(mf_plan *p, const mf_shard *s_in, const mf_entry *aos, bool swa
 			MF_TRY_HIP(hipMemcpy(p->csr_val, val.data(), nz * sizeof(double), hipMemcpyHostToDevice));
 		}
 		try {
-			bucket(s->nnz, p->items, s->col, 0, s->row, p->u0, s->val, cptr, idx, val);
+			bucket(s->nnz, p->items, s->col, 0, s->row, p->u0, s->val, cptr, idx, val, p->want_map ? &pos_c : nullptr);
 		} catch (const std::bad_alloc &) {
 			return MF_ERR_NO_MEMORY;
 		}
@@ -287,6 +315,12 @@ int build_sparse(mf_plan *p, const mf_shard *s_in, const mf_entry *aos, bool swa
 		if (nz) {
 			MF_TRY_HIP(hipMemcpy(p->csc_idx, idx.data(), nz * sizeof(int), hipMemcpyHostToDevice));
 			MF_TRY_HIP(hipMemcpy(p->csc_val, val.data(), nz * sizeof(double), hipMemcpyHostToDevice));
+		}
+		if (p->want_map) {
+			std::vector<int> map(nz + 1);
+			for (size_t n = 0; n < nz; ++n) map[(size_t) pos_r[n]] = pos_c[n];
+			MF_TRY(dev_alloc(&p->csr2csc, nz + 64));
+			if (nz) MF_TRY_HIP(hipMemcpy(p->csr2csc, map.data(), nz * sizeof(int), hipMemcpyHostToDevice));
 		}
 	} else {
 		MF_TRY(build_on_device(p, s_in, aos, swap, rptr, cptr));
@@ -418,6 +452,62 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 			MF_TRY_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
 		}
 	}
+	return MF_OK;
+}
+
+// Tables of the errors + streams iteration (mf_stream.hip.h): the CSR rows cut into segments of at most es_nch
+// entries (one wave each in the errors launch) and the task list of the streams launch -- every row of both factors,
+// longest first, so that the longest chains of dependent adds start at once.
+int plan_es_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vector<int> &cptr)
+{
+	p->es_mode = false;
+	if (!p->want_map || !p->csr2csc) return MF_OK;
+	const size_t row_bytes = (size_t) p->sweep.row_bytes, head = (size_t) p->sweep.xs_bytes;
+	int nch = (int) std::min<size_t>(64, (kLdsPerCu / 3 - head) / row_bytes);
+	if (const char *env = getenv("MF_ES_NCH")) {
+		const int v = atoi(env);
+		if (v >= 1 && v <= 64 && head + (size_t) v * row_bytes <= kLdsPerCu) nch = v;
+	}
+	if (nch < 1) return MF_OK;
+	p->es_nch = nch;
+	p->es_lds_errors = head + (size_t) nch * row_bytes;
+	p->es_lds_stream = mf::stream_lds_bytes(p->K, p->sweep.stream_nch);
+	if (p->es_lds_stream > kLdsPerCu) return MF_OK;
+	std::vector<int> srow, sbeg, send;
+	for (int u = 0; u < p->uc; ++u)
+		for (int c = rptr[(size_t) u]; c < rptr[(size_t) u + 1]; c += nch) {
+			srow.push_back(u);
+			sbeg.push_back(c);
+			send.push_back(std::min(rptr[(size_t) u + 1], c + nch));
+		}
+	std::vector<std::pair<int, int>> order;   // (-length, task)
+	order.reserve((size_t) p->uc + p->items);
+	for (int j = 0; j < p->items; ++j) order.emplace_back(-(cptr[(size_t) j + 1] - cptr[(size_t) j]), j);
+	for (int u = 0; u < p->uc; ++u) order.emplace_back(-(rptr[(size_t) u + 1] - rptr[(size_t) u]), (1 << 30) | u);
+	std::stable_sort(order.begin(), order.end(), [](const std::pair<int, int> &x, const std::pair<int, int> &y) {
+		return x.first < y.first;
+	});
+	std::vector<int> tasks(order.size());
+	for (size_t t = 0; t < order.size(); ++t) tasks[t] = order[t].second;
+	p->es_nseg = (int) srow.size();
+	p->es_ntasks = (int) tasks.size();
+	if (p->es_nseg == 0 || p->es_ntasks == 0) return MF_OK;
+	MF_TRY(dev_alloc(&p->es_seg_row, srow.size()));
+	MF_TRY(dev_alloc(&p->es_seg_beg, srow.size()));
+	MF_TRY(dev_alloc(&p->es_seg_end, srow.size()));
+	MF_TRY(dev_alloc(&p->es_tasks, tasks.size()));
+	MF_TRY(dev_alloc(&p->err_csr, (size_t) p->nnz + 64));
+	MF_TRY(dev_alloc(&p->err_csc, (size_t) p->nnz + 64));
+	MF_TRY_HIP(hipMemcpy(p->es_seg_row, srow.data(), srow.size() * sizeof(int), hipMemcpyHostToDevice));
+	MF_TRY_HIP(hipMemcpy(p->es_seg_beg, sbeg.data(), srow.size() * sizeof(int), hipMemcpyHostToDevice));
+	MF_TRY_HIP(hipMemcpy(p->es_seg_end, send.data(), srow.size() * sizeof(int), hipMemcpyHostToDevice));
+	MF_TRY_HIP(hipMemcpy(p->es_tasks, tasks.data(), tasks.size() * sizeof(int), hipMemcpyHostToDevice));
+	// the slack behind the last entry is read (never used) by the streams launch's 64-wide META transfers
+	MF_TRY_HIP(hipMemset(p->err_csr + p->nnz, 0, 64 * sizeof(double)));
+	MF_TRY_HIP(hipMemset(p->err_csc + p->nnz, 0, 64 * sizeof(double)));
+	MF_TRY_HIP(raise_lds_limit((const void *) p->sweep.errs, p->es_lds_errors));
+	MF_TRY_HIP(raise_lds_limit((const void *) p->sweep.stream, p->es_lds_stream));
+	p->es_mode = true;
 	return MF_OK;
 }
 

@@ -115,6 +115,7 @@ static int plan_create_impl(mf_plan **out, const mf_shard *s, const mf_entry *ao
 		std::vector<int> rptr, cptr;
 		MF_TRY(build_sparse(p, s, aos, swap, rptr, cptr));
 		MF_TRY(plan_row_schedule(p, rptr, cptr));
+		MF_TRY(plan_es_schedule(p, rptr, cptr));
 	}
 
 	const size_t nl = (size_t) p->uc * p->K, nr = (size_t) p->items * p->K;
@@ -155,9 +156,16 @@ void mf_plan_destroy(mf_plan *p)
 	(void) hipSetDevice(p->device);
 	if (p->stream) (void) hipStreamSynchronize(p->stream);
 	for (auto &t : p->timed) {
-		(void) hipEventDestroy(t.t0);
+		if (!t.shared_start) (void) hipEventDestroy(t.t0);
 		(void) hipEventDestroy(t.t1);
 	}
+	(void) hipFree(p->csr2csc);
+	(void) hipFree(p->err_csr);
+	(void) hipFree(p->err_csc);
+	(void) hipFree(p->es_seg_row);
+	(void) hipFree(p->es_seg_beg);
+	(void) hipFree(p->es_seg_end);
+	(void) hipFree(p->es_tasks);
 	(void) hipFree(p->csr_ptr);
 	(void) hipFree(p->csr_idx);
 	(void) hipFree(p->csr_val);
@@ -263,6 +271,14 @@ int mf_plan_flip(mf_plan *p)
 
 static int iterate_eager(mf_plan *p, int iters)
 {
+	if (p->es_mode) {
+		for (int it = 0; it < iters; ++it) {
+			const int rc = launch_es_iteration(p);
+			if (rc != MF_OK) return rc;
+			p->cur ^= 1;
+		}
+		return MF_OK;
+	}
 	for (int it = 0; it < iters; ++it) {
 		// Both sweeps read only the frozen generation (matFact.c:38-39), so the ordered sums of the item sweep's
 		// extreme rows may run on the side stream UNDER the whole user sweep; they are joined before the flip.
@@ -646,15 +662,21 @@ int mf_plan_timing_read(mf_plan *p, int64_t *item_launches, double *item_ms, int
 int mf_plan_describe(mf_plan *p, char *buf, int buflen)
 {
 	if (!p || !buf || buflen <= 0) return MF_ERR_ARGUMENT;
+	int n;
 	if (p->sweep.dma)
-		snprintf(buf, (size_t) buflen,
-		         "sweep_dma_kernel<KT=%d,NPASS=%d> K=%d nch=%d row_bytes=%d lds=%zu long_rows=%d/%d coop_nch=%d",
-		         p->sweep.kt, p->sweep.kt ? (p->K / 2 + 63) / 64 : p->sweep.kpmax, p->K, p->nch, p->sweep.row_bytes,
-		         p->lds_bytes, p->n_long[0] + (p->coop_all[0] ? p->items : 0), p->n_long[1] + (p->coop_all[1] ? p->uc : 0),
-		         p->coop_all[0] || p->coop_all[1] ? p->nch_coop : 0);
+		n = snprintf(buf, (size_t) buflen,
+		             "sweep_dma_kernel<KT=%d,NPASS=%d> K=%d nch=%d row_bytes=%d lds=%zu long_rows=%d/%d coop_nch=%d",
+		             p->sweep.kt, p->sweep.kt ? (p->K / 2 + 63) / 64 : p->sweep.kpmax, p->K, p->nch, p->sweep.row_bytes,
+		             p->lds_bytes, p->n_long[0] + (p->coop_all[0] ? p->items : 0), p->n_long[1] + (p->coop_all[1] ? p->uc : 0),
+		             p->coop_all[0] || p->coop_all[1] ? p->nch_coop : 0);
 	else
-		snprintf(buf, (size_t) buflen, "sweep_kernel<KT=%d,KPMAX=%d> K=%d nch=%d stride=%d lds=%zu",
-		         p->sweep.kt, p->sweep.kpmax, p->K, p->nch, p->stride, p->lds_bytes);
+		n = snprintf(buf, (size_t) buflen, "sweep_kernel<KT=%d,KPMAX=%d> K=%d nch=%d stride=%d lds=%zu",
+		             p->sweep.kt, p->sweep.kpmax, p->K, p->nch, p->stride, p->lds_bytes);
+	// how mf_plan_iterate runs an iteration: the two sweeps above, or errors + streams (mf_stream.hip.h)
+	if (n > 0 && n < buflen)
+		snprintf(buf + n, (size_t) (buflen - n),
+		         p->es_mode ? " iterate=errors+streams(segments=%d x<=%d, rows=%d, stream_nch=%d, lds=%zu/%zu)" : " iterate=sweeps",
+		         p->es_nseg, p->es_nch, p->es_ntasks, p->sweep.stream_nch, p->es_lds_errors, p->es_lds_stream);
 	return MF_OK;
 }
 

@@ -2,5 +2,6 @@
 #pragma once
 #include "mf_common.hip.h"
 #include "mf_sweep.hip.h"
+#include "mf_stream.hip.h"
 #include "mf_recommend.hip.h"
 #include "mf_collective.hip.h"

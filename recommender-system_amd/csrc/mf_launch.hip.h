@@ -6,7 +6,7 @@ namespace {
 int choose_sweep(mf_plan *p)
 {
 	const int K = p->K;
-	p->sweep = SweepVariant{nullptr, 0, 0, 0, 0, 0, nullptr, nullptr};
+	p->sweep = SweepVariant{nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, 0};
 	const char *impl = getenv("MF_SWEEP_IMPL");   // "dma" (default) | "reg": register-staged form only
 	const bool allow_dma = !(impl && strcmp(impl, "reg") == 0);
 	if (allow_dma)
@@ -59,6 +59,18 @@ int choose_sweep(mf_plan *p)
 	p->nch_few = few;
 	p->lds_bytes_few = head + (size_t) few * row_bytes;
 	MF_HIP(raise_lds_limit((const void *) p->sweep.fn, (size_t) (std::max(p->lds_bytes, p->lds_bytes_few))));
+	// ---- errors + streams iteration (mf_stream.hip.h) for instances whose factors stay in L2 / Infinity Cache: the
+	// two sweeps are then bound by the latency of one wave walking a row chunk by chunk, not by bandwidth.  It costs a
+	// third gather of every entry's row, so it is only chosen while the factors are cache-resident; MF_ITER_MODE=es |
+	// sweeps overrides, MF_ES_MAX_MB moves the limit.
+	p->want_map = false;
+	if (p->sweep.errs && p->sweep.stream && p->nnz > 0 && p->uc < (1 << 30) && p->items < (1 << 30)) {
+		const char *mode = getenv("MF_ITER_MODE");
+		const char *lim = getenv("MF_ES_MAX_MB");
+		const double factor_mb = ((double) p->uc + p->items) * K * 8.0 / 1048576.0;
+		const bool fits = factor_mb <= (lim ? atof(lim) : 48.0);
+		p->want_map = mode ? strcmp(mode, "es") == 0 : fits;
+	}
 	return MF_OK;
 }
 
@@ -178,6 +190,63 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 	return MF_OK;
 }
 
+// One iteration in the errors + streams form: errors launch over the CSR segments (e_n in CSR and CSC order), then
+// ONE streams launch that adds up both factors' rows (timed as kind 0 / kind 1 like the two sweeps).
+int launch_es_iteration(mf_plan *p)
+{
+	const int nxt = p->cur ^ 1;
+	mf::SweepArgs a;
+	memset(&a, 0, sizeof a);
+	a.nrows = p->es_nseg;
+	a.K = p->K;
+	a.nch = p->es_nch;
+	a.stride = p->stride;
+	a.seed = 1;
+	a.c2 = p->alpha * 2;
+	a.ptr = p->csr_ptr;
+	a.idx = p->csr_idx;
+	a.val = p->csr_val;
+	a.X_old = p->Lbuf[p->cur];
+	a.Y_old = p->Rbuf[p->cur];
+	a.X_new = nullptr;
+	a.seg_row = p->es_seg_row;
+	a.seg_beg = p->es_seg_beg;
+	a.seg_end = p->es_seg_end;
+	a.err_a = p->err_csr;
+	a.err_b = p->err_csc;
+	a.map = p->csr2csc;
+	mf::StreamArgs s;
+	s.ntasks = p->es_ntasks;
+	s.K = p->K;
+	s.tasks = p->es_tasks;
+	s.side[0] = mf::StreamSide{p->csc_ptr, p->csc_idx, p->err_csc, p->Rbuf[p->cur], p->Lbuf[p->cur], p->Rbuf[nxt]};
+	s.side[1] = mf::StreamSide{p->csr_ptr, p->csr_idx, p->err_csr, p->Lbuf[p->cur], p->Rbuf[p->cur], p->Lbuf[nxt]};
+	TimedLaunch t0{}, t1{};
+	if (p->timing) {
+		MF_HIP(hipEventCreate(&t0.t0));
+		MF_HIP(hipEventCreate(&t0.t1));
+		MF_HIP(hipEventCreate(&t1.t1));
+		t0.kind = 0;
+		t1.kind = 1;
+		MF_HIP(hipEventRecord(t0.t0, p->stream));
+	}
+	void *eargs[] = {&a};
+	MF_HIP(hipLaunchKernel((const void *) p->sweep.errs, dim3(p->es_nseg), dim3(mf::kWave), eargs, p->es_lds_errors,
+	                       p->stream));
+	if (p->timing) MF_HIP(hipEventRecord(t0.t1, p->stream));
+	void *sargs[] = {&s};
+	MF_HIP(hipLaunchKernel((const void *) p->sweep.stream, dim3(p->es_ntasks), dim3(mf::kWave), sargs, p->es_lds_stream,
+	                       p->stream));
+	if (p->timing) {
+		MF_HIP(hipEventRecord(t1.t1, p->stream));
+		t1.t0 = t0.t1;
+		t1.shared_start = true;
+		p->timed.push_back(t0);
+		p->timed.push_back(t1);
+	}
+	return MF_OK;
+}
+
 int drain_timing(mf_plan *p)
 {
 	for (auto &t : p->timed) {
@@ -186,9 +255,9 @@ int drain_timing(mf_plan *p)
 		MF_HIP(hipEventElapsedTime(&ms, t.t0, t.t1));
 		p->acc_launch[t.kind]++;
 		p->acc_ms[t.kind] += ms;
-		(void) hipEventDestroy(t.t0);
-		(void) hipEventDestroy(t.t1);
+		if (!t.shared_start) (void) hipEventDestroy(t.t0);
 	}
+	for (auto &t : p->timed) (void) hipEventDestroy(t.t1);
 	p->timed.clear();
 	return MF_OK;
 }

@@ -51,6 +51,11 @@ struct SweepArgs {
 	const long long *__restrict__ seg_out;
 	double *__restrict__ scratch;
 	size_t scratch_entries;            // entries per 16-column slice of the scratch buffer
+	// errors mode (mf_stream.hip.h): e_n of every entry of the segment goes to err_a[n] (this side's entry order) and
+	// to err_b[map[n]] (the other side's order); nothing is accumulated
+	double *__restrict__ err_a;
+	double *__restrict__ err_b;
+	const int *__restrict__ map;
 };
 
 __device__ __forceinline__ double readlane_f64(double v, int lane)
@@ -182,9 +187,12 @@ static_assert(kSliceCols == 8 || kSliceCols == 16, "slice width");
 // scaled rows p_n[k] = e_n * y_n[k] (the rounded product the serial loop adds) are stored to a scratch buffer in
 // entry order, and ordered_sum_kernel adds them up in that order afterwards.  Thousands of segments run in
 // parallel, so a row rated by every user costs a chip-wide pass plus one serial chain of adds.
-template <int KT, int NPASS, bool PRODUCTS = false>
+// MODE: 0 accumulate (the sweep), 1 products (extreme rows), 2 errors (first half of the errors + streams iteration)
+constexpr int kSweepAccumulate = 0, kSweepProducts = 1, kSweepErrors = 2;
+template <int KT, int NPASS, int MODE = kSweepAccumulate>
 __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 {
+	constexpr bool PRODUCTS = MODE == kSweepProducts, ERRORS = MODE == kSweepErrors, SEGMENTS = MODE != kSweepAccumulate;
 	const int K = KT > 0 ? KT : a.K;
 	const int P = K >> 1;                                   // 16-B pieces per row
 	constexpr int NP = NPASS;                               // DMA instructions per row
@@ -199,9 +207,9 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 	const unsigned long long ybase = (unsigned long long) a.Y_old;
 
 	for (int it = blockIdx.x; it < a.nrows; it += gridDim.x) {
-		const int r = PRODUCTS ? a.seg_row[it] : (a.rowlist ? a.rowlist[it] : it);
-		const int beg = PRODUCTS ? a.seg_beg[it] : a.ptr[r];
-		const int end = PRODUCTS ? a.seg_end[it] : a.ptr[r + 1];
+		const int r = SEGMENTS ? a.seg_row[it] : (a.rowlist ? a.rowlist[it] : it);
+		const int beg = SEGMENTS ? a.seg_beg[it] : a.ptr[r];
+		const int end = SEGMENTS ? a.seg_end[it] : a.ptr[r + 1];
 		const double2 *__restrict__ xrow2 = reinterpret_cast<const double2 *>(a.X_old + (size_t) r * K);
 
 		double2 acc[NP];
@@ -217,19 +225,22 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 		}
 
 		// (idx, val) of a chunk are loaded one chunk ahead, so the gather of chunk c never waits on them
-		int nx_idx = 0;
+		int nx_idx = 0, nx_map = 0;
 		double nx_val = 0.0;
 		if (beg + lane < min(end, beg + nch)) {
 			nx_idx = a.idx[beg + lane];
 			nx_val = a.val[beg + lane];
+			if (ERRORS) nx_map = a.map[beg + lane];
 		}
 		for (int c = beg; c < end; c += nch) {
 			const int cnt = min(nch, end - c);
 			const int my_idx = nx_idx;
+			const int my_map = nx_map;
 			const double my_val = nx_val;
 			if (c + nch + lane < min(end, c + 2 * nch)) {
 				nx_idx = a.idx[c + nch + lane];
 				nx_val = a.val[c + nch + lane];
+				if (ERRORS) nx_map = a.map[c + nch + lane];
 			}
 			// ---- stage.  Short rows (K <= 62) are gathered SEVERAL per instruction: lane -> (row lane / PS, piece
 			// lane % PS) with PS = the tile row stride in pieces (P, or P + 1 when P is even: that lane is the padding
@@ -296,6 +307,14 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 				}
 				e = a.c2 * (my_val - dot);
 			}
+			if (ERRORS) {
+				if (lane < cnt) {
+					a.err_a[c + lane] = e;
+					a.err_b[my_map] = e;
+				}
+				__syncthreads();   // tile is overwritten by the next chunk's DMA
+				continue;
+			}
 			if (PRODUCTS) {
 				// scratch layout: [k-slice][entry][kSliceCols doubles] -- a slice is contiguous over the entries, so
 				// ordered_sum_kernel streams it linearly
@@ -354,7 +373,7 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 			}
 			__syncthreads();   // tile is overwritten by the next chunk's DMA
 		}
-		if (!PRODUCTS) {
+		if (!SEGMENTS) {
 			double2 *__restrict__ out2 = reinterpret_cast<double2 *>(a.X_new + (size_t) r * K);
 #pragma unroll
 			for (int p = 0; p < NP; ++p) {

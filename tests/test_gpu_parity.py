@@ -21,6 +21,15 @@ def _need_gpu(capi):
         pytest.fail("GPU tests need an MI355X; mf_backend_device_count() = %d" % capi.device_count())
 
 
+@pytest.fixture(params=["auto", "sweeps"], autouse=True)
+def iter_mode(request, monkeypatch):
+    """Every test runs twice: with the iteration form the plan picks by itself (errors + streams for cache-resident
+    factors, mf_stream.hip.h) and with the two sweeps forced, so that both stay pinned on the oracle."""
+    if request.param == "sweeps":
+        monkeypatch.setenv("MF_ITER_MODE", "sweeps")
+    return request.param
+
+
 def _inst(capi, d):
     return capi.Instance(d["iters"], d["alpha"], d["feats"], d["users"], d["items"], d["row"], d["col"], d["val"])
 
@@ -953,3 +962,76 @@ def test_multi_setup_does_not_grow_with_the_shard_count(capi, monkeypatch):
     assert (res["eight"][2] != res["one"][2]).sum() <= 2    # a near-tie may resolve differently after re-association
     print("multi set-up 1 shard %.3f s, 8 shards %.3f s; recommend %.3f / %.3f s" % (
         t1["setup_s"], t8["setup_s"], t1["recommend_s"], t8["recommend_s"]))
+
+
+# ------------------------------------------------------------------ errors + streams iteration (mf_stream.hip.h)
+@pytest.mark.parametrize("k", [10, 20, 30, 50, 100, 128, 256, 2, 64, 96, 200, 300, 1024])
+def test_errors_plus_streams_iteration_bit_exact_for_every_k(capi, orc, k, monkeypatch):
+    """MF_ITER_MODE=es forced: the errors launch (one wave per <= 64-entry segment of a CSR row) + the streams launch
+    (one wave per row of either factor, LDS-DMA rings with hand-counted vmcnt) against the serial oracle, bit for bit.
+    Rows of every kind: empty, one entry, one chunk, exactly D+1 chunks (the last `short row` case), one entry more
+    (the first pipelined case), and long ones (hundreds of chunks at large K)."""
+    monkeypatch.setenv("MF_ITER_MODE", "es")
+    rng = np.random.default_rng(900 + k)
+    U, I = 70, 1100
+    nch = {10: 64, 20: 64, 30: 64, 50: 32}.get(k, max(1, 16 // ((k // 2 + 63) // 64)) if k not in (100, 128) else 16)
+    lens = [0, 1, 2, nch - 1, nch, nch + 1, 4 * nch - 1, 4 * nch, 4 * nch + 1, 5 * nch, 7 * nch + 3, 1000, 1100]
+    lens = [min(x, I) for x in lens] + list(rng.integers(0, min(I, 6 * nch + 40), U - len(lens)))
+    rows, cols = [], []
+    for u, m in enumerate(lens):
+        c = np.sort(rng.choice(I, int(m), replace=False))
+        rows.append(np.full(len(c), u))
+        cols.append(c)
+    row = np.concatenate(rows).astype(np.int32)
+    col = np.concatenate(cols).astype(np.int32)
+    d = dict(iters=3, alpha=3e-4, feats=k, users=U, items=I, row=row, col=col,
+             val=(rng.random(len(row)) * 4 + 1))
+    plan = capi.Plan(U, I, k, d["alpha"], row, col, d["val"])
+    assert "iterate=errors+streams" in plan.describe(), plan.describe()
+    L, R = capi.init_factors(U, I, k)
+    plan.upload(L, R)
+    plan.iterate(3)
+    Lg, Rg = plan.download()
+    plan.close()
+    Lo, Ro, bo = _oracle_run(orc, d)
+    assert np.array_equal(Lg, Lo), "L differs"
+    assert np.array_equal(Rg, Ro), "R differs"
+
+
+def test_errors_plus_streams_unsorted_input_and_graph_replay(capi, orc, monkeypatch):
+    """File order that is neither row- nor column-sorted (the CSR -> CSC position map then goes through the inverse of
+    the row permutation), 200 iterations so that mf_plan_iterate replays the captured pair of launches from a HIP
+    graph, host- and device-built tables."""
+    monkeypatch.setenv("MF_ITER_MODE", "es")
+    d = random_instance(77, 90, 70, 30, density=0.3, iters=200, alpha=0.002, empty_rows=(4,), full_rows=(9,))
+    perm = np.random.default_rng(5).permutation(len(d["row"]))
+    dp = dict(d, row=np.ascontiguousarray(d["row"][perm]), col=np.ascontiguousarray(d["col"][perm]),
+              val=np.ascontiguousarray(d["val"][perm]))
+    Lo, Ro = orc.init_factors(90, 70, 30)
+    orc.factorize(orc.Instance(**dp), Lo, Ro)
+    for build in ("device", "host"):
+        monkeypatch.setenv("MF_BUILD", build)
+        L, R = capi.init_factors(90, 70, 30)
+        capi.backend_factorize(_inst(capi, dp), L, R)
+        assert np.array_equal(L, Lo) and np.array_equal(R, Ro), build
+
+
+def test_iteration_forms_agree_on_ml100k_and_report_their_timing(capi, monkeypatch):
+    """instML100k (BASELINE.json configs[1]): both iteration forms give the golden factors after 40 iterations; the
+    per-launch timing interface reports one errors and one streams launch per iteration."""
+    inst = capi.parse_file(golden_in("instML100k"))
+    L0, R0 = capi.init_factors(inst.users, inst.items, inst.feats)
+    res = {}
+    for mode in ("es", "sweeps"):
+        monkeypatch.setenv("MF_ITER_MODE", mode)
+        plan = capi.Plan(inst.users, inst.items, inst.feats, inst.alpha, inst.row, inst.col, inst.val)
+        assert ("errors+streams" in plan.describe()) == (mode == "es")
+        plan.upload(L0, R0)
+        plan.timing(True)
+        plan.iterate(40)
+        plan.timing(False)
+        tm = plan.timing_read()
+        assert tm["item_launches"] == 40 and tm["user_launches"] == 40
+        res[mode] = plan.download()
+        plan.close()
+    assert np.array_equal(res["es"][0], res["sweeps"][0]) and np.array_equal(res["es"][1], res["sweeps"][1])
