@@ -110,6 +110,13 @@ __global__ void __launch_bounds__(256) csr2csc_kernel(const unsigned *__restrict
 	map[file2csr ? file2csr[f] : (int) f] = (int) q;
 }
 
+__global__ void __launch_bounds__(256) fill_records_kernel(const int *__restrict__ idx, int64_t nnz,
+                                                           mf::StreamRec *__restrict__ rec)
+{
+	const int64_t n = (int64_t) blockIdx.x * 256 + threadIdx.x;
+	if (n < nnz) rec[n].idx = idx[n];
+}
+
 int bits_for(int nkeys)
 {
 	int b = 1;
@@ -456,8 +463,9 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 }
 
 // Tables of the errors + streams iteration (mf_stream.hip.h): the CSR rows cut into segments of at most es_nch
-// entries (one wave each in the errors launch) and the task list of the streams launch -- every row of both factors,
-// longest first, so that the longest chains of dependent adds start at once.
+// entries (one wave each in the errors launch) and the chunk list of the streams launch -- every (row, column slice) of
+// both factors cut into chunks of at most 64 entries -- dealt to the persistent waves in contiguous ranges of whole
+// rows, balanced by cost.
 int plan_es_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vector<int> &cptr)
 {
 	p->es_mode = false;
@@ -471,8 +479,6 @@ int plan_es_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vector
 	if (nch < 1) return MF_OK;
 	p->es_nch = nch;
 	p->es_lds_errors = head + (size_t) nch * row_bytes;
-	p->es_lds_stream = mf::stream_lds_bytes(p->K, p->sweep.stream_nch);
-	if (p->es_lds_stream > kLdsPerCu) return MF_OK;
 	std::vector<int> srow, sbeg, send;
 	for (int u = 0; u < p->uc; ++u)
 		for (int c = rptr[(size_t) u]; c < rptr[(size_t) u + 1]; c += nch) {
@@ -480,33 +486,91 @@ int plan_es_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vector
 			sbeg.push_back(c);
 			send.push_back(std::min(rptr[(size_t) u + 1], c + nch));
 		}
-	std::vector<std::pair<int, int>> order;   // (-length, task)
-	order.reserve((size_t) p->uc + p->items);
-	for (int j = 0; j < p->items; ++j) order.emplace_back(-(cptr[(size_t) j + 1] - cptr[(size_t) j]), j);
-	for (int u = 0; u < p->uc; ++u) order.emplace_back(-(rptr[(size_t) u + 1] - rptr[(size_t) u]), (1 << 30) | u);
-	std::stable_sort(order.begin(), order.end(), [](const std::pair<int, int> &x, const std::pair<int, int> &y) {
-		return x.first < y.first;
-	});
-	std::vector<int> tasks(order.size());
-	for (size_t t = 0; t < order.size(); ++t) tasks[t] = order[t].second;
+	// column slices: ns slices of sp 16-byte pieces each (the last one may hold fewer), sp <= 8
+	const int P = p->K / 2, ns = (P + mf::kStreamSlicePieces - 1) / mf::kStreamSlicePieces, sp = (P + ns - 1) / ns;
+	p->es_sp = sp;
+	// chunk list: (side, slice, row) in that order, rows cut into chunks of <= 64 entries; cost of a chunk ~ its
+	// entries + a fixed share for the transfers and waits
+	std::vector<mf::StreamChunk> chunks;
+	std::vector<double> row_cost;     // per (side, slice, row)
+	std::vector<int> row_first;       // its first chunk
+	for (int side = 0; side < 2; ++side) {
+		const std::vector<int> &pt = side == 0 ? cptr : rptr;
+		const int nrows = side == 0 ? p->items : p->uc;
+		for (int sl = 0; sl < ns; ++sl)
+			for (int r = 0; r < nrows; ++r) {
+				const int b = pt[(size_t) r], e = pt[(size_t) r + 1];
+				row_first.push_back((int) chunks.size());
+				double cost = 0;
+				int c = b;
+				do {
+					const int cnt = std::min(mf::kStreamChunk, e - c);
+					int fl = cnt;
+					if (c == b) fl |= mf::kStreamFirst;
+					if (c + cnt >= e) fl |= mf::kStreamLast;
+					chunks.push_back(mf::StreamChunk{c, fl, (side << 30) | (sl << 24) | r, 0});
+					cost += cnt + 24;
+					c += cnt;
+				} while (c < e);
+				row_cost.push_back(cost);
+			}
+	}
+	row_first.push_back((int) chunks.size());
+	// contiguous ranges of whole rows per wave, balanced by cost
+	int ncu = 256;
+	{
+		hipDeviceProp_t prop;
+		if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+	}
+	int nwaves = mf::kStreamWavesPerCu * ncu;
+	if (const char *env = getenv("MF_ES_WAVES")) nwaves = std::max(1, atoi(env));
+	double total = 0;
+	for (double c : row_cost) total += c;
+	std::vector<int> wave_beg(1, 0);
+	{
+		double acc_cost = 0, done = 0;
+		for (size_t i = 0; i < row_cost.size(); ++i) {
+			acc_cost += row_cost[i];
+			const int left = nwaves - (int) wave_beg.size();
+			const double target = left > 0 ? (total - done) / (left + 1) : total;
+			if (acc_cost >= target && left > 0 && i + 1 < row_cost.size()) {
+				wave_beg.push_back(row_first[i + 1]);
+				done += acc_cost;
+				acc_cost = 0;
+			}
+		}
+		wave_beg.push_back((int) chunks.size());
+	}
+	p->es_ntasks = (int) wave_beg.size() - 1;
+	p->es_nrows = (int) chunks.size();
 	p->es_nseg = (int) srow.size();
-	p->es_ntasks = (int) tasks.size();
 	if (p->es_nseg == 0 || p->es_ntasks == 0) return MF_OK;
 	MF_TRY(dev_alloc(&p->es_seg_row, srow.size()));
 	MF_TRY(dev_alloc(&p->es_seg_beg, srow.size()));
 	MF_TRY(dev_alloc(&p->es_seg_end, srow.size()));
-	MF_TRY(dev_alloc(&p->es_tasks, tasks.size()));
-	MF_TRY(dev_alloc(&p->err_csr, (size_t) p->nnz + 64));
-	MF_TRY(dev_alloc(&p->err_csc, (size_t) p->nnz + 64));
+	MF_TRY(dev_alloc(&p->es_tasks, wave_beg.size()));
+	chunks.push_back(mf::StreamChunk{0, 0, 0, 0});   // slack: the waves prefetch one descriptor past their range
+	MF_TRY(dev_alloc(&p->es_chunks, chunks.size()));
+	MF_TRY(dev_alloc(&p->rec_csr, (size_t) p->nnz + 64));
+	MF_TRY(dev_alloc(&p->rec_csc, (size_t) p->nnz + 64));
 	MF_TRY_HIP(hipMemcpy(p->es_seg_row, srow.data(), srow.size() * sizeof(int), hipMemcpyHostToDevice));
 	MF_TRY_HIP(hipMemcpy(p->es_seg_beg, sbeg.data(), srow.size() * sizeof(int), hipMemcpyHostToDevice));
 	MF_TRY_HIP(hipMemcpy(p->es_seg_end, send.data(), srow.size() * sizeof(int), hipMemcpyHostToDevice));
-	MF_TRY_HIP(hipMemcpy(p->es_tasks, tasks.data(), tasks.size() * sizeof(int), hipMemcpyHostToDevice));
-	// the slack behind the last entry is read (never used) by the streams launch's 64-wide META transfers
-	MF_TRY_HIP(hipMemset(p->err_csr + p->nnz, 0, 64 * sizeof(double)));
-	MF_TRY_HIP(hipMemset(p->err_csc + p->nnz, 0, 64 * sizeof(double)));
+	MF_TRY_HIP(hipMemcpy(p->es_tasks, wave_beg.data(), wave_beg.size() * sizeof(int), hipMemcpyHostToDevice));
+	MF_TRY_HIP(hipMemcpy(p->es_chunks, chunks.data(), chunks.size() * sizeof(mf::StreamChunk), hipMemcpyHostToDevice));
+	// records = {idx (fixed), pad, err (rewritten every iteration)}; the 64 entries of slack behind the last one are
+	// read (never used) by the streams launch's 64-wide META transfers
+	MF_TRY_HIP(hipMemset(p->rec_csr, 0, ((size_t) p->nnz + 64) * sizeof(mf::StreamRec)));
+	MF_TRY_HIP(hipMemset(p->rec_csc, 0, ((size_t) p->nnz + 64) * sizeof(mf::StreamRec)));
+	{
+		const unsigned grid = (unsigned) ((p->nnz + 255) / 256);
+		hipLaunchKernelGGL(fill_records_kernel, dim3(grid), dim3(256), 0, p->stream, p->csr_idx, p->nnz, p->rec_csr);
+		hipLaunchKernelGGL(fill_records_kernel, dim3(grid), dim3(256), 0, p->stream, p->csc_idx, p->nnz, p->rec_csc);
+		MF_TRY_HIP(hipGetLastError());
+		MF_TRY_HIP(hipStreamSynchronize(p->stream));
+	}
 	MF_TRY_HIP(raise_lds_limit((const void *) p->sweep.errs, p->es_lds_errors));
-	MF_TRY_HIP(raise_lds_limit((const void *) p->sweep.stream, p->es_lds_stream));
+	MF_TRY_HIP(raise_lds_limit((const void *) mf::stream_kernel, mf::kStreamLdsBytes));
 	p->es_mode = true;
 	return MF_OK;
 }

@@ -160,12 +160,13 @@ void mf_plan_destroy(mf_plan *p)
 		(void) hipEventDestroy(t.t1);
 	}
 	(void) hipFree(p->csr2csc);
-	(void) hipFree(p->err_csr);
-	(void) hipFree(p->err_csc);
+	(void) hipFree(p->rec_csr);
+	(void) hipFree(p->rec_csc);
 	(void) hipFree(p->es_seg_row);
 	(void) hipFree(p->es_seg_beg);
 	(void) hipFree(p->es_seg_end);
 	(void) hipFree(p->es_tasks);
+	(void) hipFree(p->es_chunks);
 	(void) hipFree(p->csr_ptr);
 	(void) hipFree(p->csr_idx);
 	(void) hipFree(p->csr_val);
@@ -675,8 +676,9 @@ int mf_plan_describe(mf_plan *p, char *buf, int buflen)
 	// how mf_plan_iterate runs an iteration: the two sweeps above, or errors + streams (mf_stream.hip.h)
 	if (n > 0 && n < buflen)
 		snprintf(buf + n, (size_t) (buflen - n),
-		         p->es_mode ? " iterate=errors+streams(segments=%d x<=%d, rows=%d, stream_nch=%d, lds=%zu/%zu)" : " iterate=sweeps",
-		         p->es_nseg, p->es_nch, p->es_ntasks, p->sweep.stream_nch, p->es_lds_errors, p->es_lds_stream);
+		         p->es_mode ? " iterate=errors+streams(segments=%d x<=%d, chunks=%d of %d-piece slices on %d waves, lds=%zu/%zu)"
+		                    : " iterate=sweeps",
+		         p->es_nseg, p->es_nch, p->es_nrows, p->es_sp, p->es_ntasks, p->es_lds_errors, mf::kStreamLdsBytes);
 	return MF_OK;
 }
 

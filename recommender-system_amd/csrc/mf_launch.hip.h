@@ -6,7 +6,7 @@ namespace {
 int choose_sweep(mf_plan *p)
 {
 	const int K = p->K;
-	p->sweep = SweepVariant{nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, 0};
+	p->sweep = SweepVariant{nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr};
 	const char *impl = getenv("MF_SWEEP_IMPL");   // "dma" (default) | "reg": register-staged form only
 	const bool allow_dma = !(impl && strcmp(impl, "reg") == 0);
 	if (allow_dma)
@@ -64,7 +64,8 @@ int choose_sweep(mf_plan *p)
 	// third gather of every entry's row, so it is only chosen while the factors are cache-resident; MF_ITER_MODE=es |
 	// sweeps overrides, MF_ES_MAX_MB moves the limit.
 	p->want_map = false;
-	if (p->sweep.errs && p->sweep.stream && p->nnz > 0 && p->uc < (1 << 30) && p->items < (1 << 30)) {
+	if (p->sweep.errs && p->nnz > 0 && p->uc < (1 << 24) && p->items < (1 << 24) &&
+	    ((double) p->uc + p->items) * ((K / 2 + 7) / 8) < (double) (1 << 27)) {
 		const char *mode = getenv("MF_ITER_MODE");
 		const char *lim = getenv("MF_ES_MAX_MB");
 		const double factor_mb = ((double) p->uc + p->items) * K * 8.0 / 1048576.0;
@@ -212,15 +213,24 @@ int launch_es_iteration(mf_plan *p)
 	a.seg_row = p->es_seg_row;
 	a.seg_beg = p->es_seg_beg;
 	a.seg_end = p->es_seg_end;
-	a.err_a = p->err_csr;
-	a.err_b = p->err_csc;
+	a.err_a = reinterpret_cast<double *>(p->rec_csr);
+	a.err_b = reinterpret_cast<double *>(p->rec_csc);
 	a.map = p->csr2csc;
 	mf::StreamArgs s;
-	s.ntasks = p->es_ntasks;
+	s.nwaves = p->es_ntasks;
 	s.K = p->K;
-	s.tasks = p->es_tasks;
-	s.side[0] = mf::StreamSide{p->csc_ptr, p->csc_idx, p->err_csc, p->Rbuf[p->cur], p->Lbuf[p->cur], p->Rbuf[nxt]};
-	s.side[1] = mf::StreamSide{p->csr_ptr, p->csr_idx, p->err_csr, p->Lbuf[p->cur], p->Rbuf[p->cur], p->Lbuf[nxt]};
+	s.sp = p->es_sp;
+	s.dbg = getenv("MF_ES_DBG") ? atoi(getenv("MF_ES_DBG")) : 0;
+	s.stamps = nullptr;
+	static unsigned *g_stamps = nullptr;   // timing experiments only
+	if (s.dbg & 64) {
+		if (!g_stamps) MF_HIP(hipMalloc((void **) &g_stamps, (size_t) 4096 * 64 * sizeof(unsigned)));
+		s.stamps = g_stamps;
+	}
+	s.wave_beg = p->es_tasks;
+	s.chunks = p->es_chunks;
+	s.side[0] = mf::StreamSide{p->rec_csc, p->Rbuf[p->cur], p->Lbuf[p->cur], p->Rbuf[nxt]};
+	s.side[1] = mf::StreamSide{p->rec_csr, p->Lbuf[p->cur], p->Rbuf[p->cur], p->Lbuf[nxt]};
 	TimedLaunch t0{}, t1{};
 	if (p->timing) {
 		MF_HIP(hipEventCreate(&t0.t0));
@@ -235,8 +245,23 @@ int launch_es_iteration(mf_plan *p)
 	                       p->stream));
 	if (p->timing) MF_HIP(hipEventRecord(t0.t1, p->stream));
 	void *sargs[] = {&s};
-	MF_HIP(hipLaunchKernel((const void *) p->sweep.stream, dim3(p->es_ntasks), dim3(mf::kWave), sargs, p->es_lds_stream,
-	                       p->stream));
+	MF_HIP(hipLaunchKernel((const void *) mf::stream_kernel, dim3(p->es_ntasks), dim3(mf::kWave), sargs,
+	                       mf::kStreamLdsBytes, p->stream));
+	if ((s.dbg & 64) && getenv("MF_ES_STAMPS")) {
+		// dump the stamps of this launch (one line per wave: step deltas), debugging aid only
+		std::vector<unsigned> h((size_t) p->es_ntasks * 64);
+		MF_HIP(hipStreamSynchronize(p->stream));
+		MF_HIP(hipMemcpy(h.data(), g_stamps, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+		FILE *f = fopen(getenv("MF_ES_STAMPS"), "w");
+		if (f) {
+			for (int w = 0; w < p->es_ntasks; ++w) {
+				fprintf(f, "wave %d:", w);
+				for (int l = 0; l < 64; ++l) fprintf(f, " %u", h[(size_t) w * 64 + l]);
+				fprintf(f, "\n");
+			}
+			fclose(f);
+		}
+	}
 	if (p->timing) {
 		MF_HIP(hipEventRecord(t1.t1, p->stream));
 		t1.t0 = t0.t1;

@@ -42,14 +42,12 @@ struct SweepVariant {
 	SweepFn coop;   // row-cooperative form for tiny sweeps (compile-time-K DMA variants only)
 	SweepFn prod;   // products form for segments of extreme rows (all DMA variants)
 	SweepFn errs;   // errors form: e_n per entry of a segment (all DMA variants; mf_stream.hip.h)
-	void (*stream)(mf::StreamArgs);   // ordered accumulation of both factors from the stored errors
-	int stream_nch; // its chunk size (compile-time in the kernel)
 };
 
 template <int KT, int KP>
 constexpr SweepVariant variant()
 {
-	return SweepVariant{mf::sweep_kernel<KT, KP>, KT, KP, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, 0};
+	return SweepVariant{mf::sweep_kernel<KT, KP>, KT, KP, 0, 0, 0, nullptr, nullptr, nullptr};
 }
 
 template <int KT>
@@ -58,9 +56,7 @@ constexpr SweepVariant dma_variant()
 	return SweepVariant{mf::sweep_dma_kernel<KT, mf::DmaGeom<KT>::kPasses>, KT, 0, 1, mf::DmaGeom<KT>::kStride,
 	                    mf::DmaGeom<KT>::kXsBytes, mf::sweep_coop_kernel<KT>,
 	                    mf::sweep_dma_kernel<KT, mf::DmaGeom<KT>::kPasses, mf::kSweepProducts>,
-	                    mf::sweep_dma_kernel<KT, mf::DmaGeom<KT>::kPasses, mf::kSweepErrors>,
-	                    mf::stream_kernel<KT, mf::DmaGeom<KT>::kPasses>,
-	                    mf::StreamGeom<KT, mf::DmaGeom<KT>::kPasses>::kNch};
+	                    mf::sweep_dma_kernel<KT, mf::DmaGeom<KT>::kPasses, mf::kSweepErrors>};
 }
 
 // run-time even K <= 128 * NPASS through the LDS-DMA kernel (row_bytes / xs_bytes filled in per plan)
@@ -68,8 +64,7 @@ template <int NPASS>
 constexpr SweepVariant dma_generic_variant()
 {
 	return SweepVariant{mf::sweep_dma_kernel<0, NPASS>, 0, NPASS, 1, 0, 0, nullptr,
-	                    mf::sweep_dma_kernel<0, NPASS, mf::kSweepProducts>, mf::sweep_dma_kernel<0, NPASS, mf::kSweepErrors>,
-	                    mf::stream_kernel<0, NPASS>, mf::StreamGeom<0, NPASS>::kNch};
+	                    mf::sweep_dma_kernel<0, NPASS, mf::kSweepProducts>, mf::sweep_dma_kernel<0, NPASS, mf::kSweepErrors>};
 }
 
 // K-specialised instances for the K of the bundled samples and of the BASELINE configs, then generic ones.
@@ -116,14 +111,15 @@ struct mf_plan {
 	double *csr_val = nullptr;
 	int *csc_ptr = nullptr, *csc_idx = nullptr;
 	double *csc_val = nullptr;
-	// errors + streams iteration (mf_stream.hip.h): CSR position -> CSC position, e_n in both orders, the segment table
+	// errors + streams iteration (mf_stream.hip.h): CSR position -> CSC position, the {idx, e_n} records in both orders, the segment table
 	// of the errors launch and the task list (both factors' rows, longest first) of the streams launch
 	bool want_map = false, es_mode = false;
 	int *csr2csc = nullptr;
-	double *err_csr = nullptr, *err_csc = nullptr;
-	int es_nseg = 0, es_ntasks = 0, es_nch = 0;
-	size_t es_lds_errors = 0, es_lds_stream = 0;
+	mf::StreamRec *rec_csr = nullptr, *rec_csc = nullptr;
+	int es_nseg = 0, es_ntasks = 0, es_nch = 0, es_sp = 0, es_nrows = 0;
+	size_t es_lds_errors = 0;
 	int *es_seg_row = nullptr, *es_seg_beg = nullptr, *es_seg_end = nullptr, *es_tasks = nullptr;
+	mf::StreamChunk *es_chunks = nullptr;
 
 	double *Lbuf[2] = {nullptr, nullptr};
 	double *Rbuf[2] = {nullptr, nullptr};

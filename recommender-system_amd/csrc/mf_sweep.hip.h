@@ -51,8 +51,8 @@ struct SweepArgs {
 	const long long *__restrict__ seg_out;
 	double *__restrict__ scratch;
 	size_t scratch_entries;            // entries per 16-column slice of the scratch buffer
-	// errors mode (mf_stream.hip.h): e_n of every entry of the segment goes to err_a[n] (this side's entry order) and
-	// to err_b[map[n]] (the other side's order); nothing is accumulated
+	// errors mode (mf_stream.hip.h): e_n of every entry of the segment goes to the 16-byte records {idx, pad, err} of
+	// both sides -- record n of err_a (this side's entry order), record map[n] of err_b; nothing is accumulated
 	double *__restrict__ err_a;
 	double *__restrict__ err_b;
 	const int *__restrict__ map;
@@ -309,8 +309,8 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 			}
 			if (ERRORS) {
 				if (lane < cnt) {
-					a.err_a[c + lane] = e;
-					a.err_b[my_map] = e;
+					a.err_a[2 * (size_t) (c + lane) + 1] = e;
+					a.err_b[2 * (size_t) my_map + 1] = e;
 				}
 				__syncthreads();   // tile is overwritten by the next chunk's DMA
 				continue;

@@ -969,13 +969,15 @@ def test_multi_setup_does_not_grow_with_the_shard_count(capi, monkeypatch):
 def test_errors_plus_streams_iteration_bit_exact_for_every_k(capi, orc, k, monkeypatch):
     """MF_ITER_MODE=es forced: the errors launch (one wave per <= 64-entry segment of a CSR row) + the streams launch
     (one wave per row of either factor, LDS-DMA rings with hand-counted vmcnt) against the serial oracle, bit for bit.
-    Rows of every kind: empty, one entry, one chunk, exactly D+1 chunks (the last `short row` case), one entry more
-    (the first pipelined case), and long ones (hundreds of chunks at large K)."""
+    Rows of every kind: empty, one entry, exactly one chunk (the last bundled case), one entry more (the first
+    pipelined case), every chunk count around the ring depths, and rows of up to 18 chunks; every K gives a different
+    number and width of column slices."""
     monkeypatch.setenv("MF_ITER_MODE", "es")
     rng = np.random.default_rng(900 + k)
     U, I = 70, 1100
-    nch = {10: 64, 20: 64, 30: 64, 50: 32}.get(k, max(1, 16 // ((k // 2 + 63) // 64)) if k not in (100, 128) else 16)
-    lens = [0, 1, 2, nch - 1, nch, nch + 1, 4 * nch - 1, 4 * nch, 4 * nch + 1, 5 * nch, 7 * nch + 3, 1000, 1100]
+    nch = 64     # chunk of the streams launch; 5 tile slots: rows of <= 64 entries are bundled five to a wave
+    lens = [0, 1, 2, nch - 1, nch, nch + 1, 2 * nch, 4 * nch - 1, 4 * nch, 4 * nch + 1, 5 * nch, 5 * nch + 1, 7 * nch + 3,
+            9 * nch, 1000, 1100]
     lens = [min(x, I) for x in lens] + list(rng.integers(0, min(I, 6 * nch + 40), U - len(lens)))
     rows, cols = [], []
     for u, m in enumerate(lens):
