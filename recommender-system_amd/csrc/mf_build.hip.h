@@ -463,9 +463,7 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 }
 
 // Tables of the errors + streams iteration (mf_stream.hip.h): the CSR rows cut into segments of at most es_nch
-// entries (one wave each in the errors launch) and the chunk list of the streams launch -- every (row, column slice) of
-// both factors cut into chunks of at most 64 entries -- dealt to the persistent waves in contiguous ranges of whole
-// rows, balanced by cost.
+// entries (one wave each in the errors launch) and the workgroup table of the streams launch (mf_resident.hip.h).
 int plan_es_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vector<int> &cptr)
 {
 	p->es_mode = false;
@@ -486,80 +484,23 @@ int plan_es_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vector
 			sbeg.push_back(c);
 			send.push_back(std::min(rptr[(size_t) u + 1], c + nch));
 		}
-	// column slices: ns slices of sp 16-byte pieces each (the last one may hold fewer), sp <= 8
-	const int P = p->K / 2, ns = (P + mf::kStreamSlicePieces - 1) / mf::kStreamSlicePieces, sp = (P + ns - 1) / ns;
-	p->es_sp = sp;
-	// chunk list: (side, slice, row) in that order, rows cut into chunks of <= 64 entries; cost of a chunk ~ its
-	// entries + a fixed share for the transfers and waits
-	std::vector<mf::StreamChunk> chunks;
-	std::vector<double> row_cost;     // per (side, slice, row)
-	std::vector<int> row_first;       // its first chunk
-	for (int side = 0; side < 2; ++side) {
-		const std::vector<int> &pt = side == 0 ? cptr : rptr;
-		const int nrows = side == 0 ? p->items : p->uc;
-		for (int sl = 0; sl < ns; ++sl)
-			for (int r = 0; r < nrows; ++r) {
-				const int b = pt[(size_t) r], e = pt[(size_t) r + 1];
-				row_first.push_back((int) chunks.size());
-				double cost = 0;
-				int c = b;
-				do {
-					const int cnt = std::min(mf::kStreamChunk, e - c);
-					int fl = cnt;
-					if (c == b) fl |= mf::kStreamFirst;
-					if (c + cnt >= e) fl |= mf::kStreamLast;
-					chunks.push_back(mf::StreamChunk{c, fl, (side << 30) | (sl << 24) | r, 0});
-					cost += cnt + 24;
-					c += cnt;
-				} while (c < e);
-				row_cost.push_back(cost);
-			}
-	}
-	row_first.push_back((int) chunks.size());
-	// contiguous ranges of whole rows per wave, balanced by cost
 	int ncu = 256;
 	{
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
 	}
-	int nwaves = mf::kStreamWavesPerCu * ncu;
-	if (const char *env = getenv("MF_ES_WAVES")) nwaves = std::max(1, atoi(env));
-	double total = 0;
-	for (double c : row_cost) total += c;
-	std::vector<int> wave_beg(1, 0);
-	{
-		double acc_cost = 0, done = 0;
-		for (size_t i = 0; i < row_cost.size(); ++i) {
-			acc_cost += row_cost[i];
-			const int left = nwaves - (int) wave_beg.size();
-			const double target = left > 0 ? (total - done) / (left + 1) : total;
-			if (acc_cost >= target && left > 0 && i + 1 < row_cost.size()) {
-				wave_beg.push_back(row_first[i + 1]);
-				done += acc_cost;
-				acc_cost = 0;
-			}
-		}
-		wave_beg.push_back((int) chunks.size());
-	}
-	p->es_ntasks = (int) wave_beg.size() - 1;
-	p->es_nrows = (int) chunks.size();
 	p->es_nseg = (int) srow.size();
-	if (p->es_nseg == 0 || p->es_ntasks == 0) return MF_OK;
+	if (p->es_nseg == 0 || p->res_sw <= 0) return MF_OK;
 	MF_TRY(dev_alloc(&p->es_seg_row, srow.size()));
 	MF_TRY(dev_alloc(&p->es_seg_beg, srow.size()));
 	MF_TRY(dev_alloc(&p->es_seg_end, srow.size()));
-	MF_TRY(dev_alloc(&p->es_tasks, wave_beg.size()));
-	chunks.push_back(mf::StreamChunk{0, 0, 0, 0});   // slack: the waves prefetch one descriptor past their range
-	MF_TRY(dev_alloc(&p->es_chunks, chunks.size()));
 	MF_TRY(dev_alloc(&p->rec_csr, (size_t) p->nnz + 64));
 	MF_TRY(dev_alloc(&p->rec_csc, (size_t) p->nnz + 64));
 	MF_TRY_HIP(hipMemcpy(p->es_seg_row, srow.data(), srow.size() * sizeof(int), hipMemcpyHostToDevice));
 	MF_TRY_HIP(hipMemcpy(p->es_seg_beg, sbeg.data(), srow.size() * sizeof(int), hipMemcpyHostToDevice));
 	MF_TRY_HIP(hipMemcpy(p->es_seg_end, send.data(), srow.size() * sizeof(int), hipMemcpyHostToDevice));
-	MF_TRY_HIP(hipMemcpy(p->es_tasks, wave_beg.data(), wave_beg.size() * sizeof(int), hipMemcpyHostToDevice));
-	MF_TRY_HIP(hipMemcpy(p->es_chunks, chunks.data(), chunks.size() * sizeof(mf::StreamChunk), hipMemcpyHostToDevice));
 	// records = {idx (fixed), pad, err (rewritten every iteration)}; the 64 entries of slack behind the last one are
-	// read (never used) by the streams launch's 64-wide META transfers
+	// read (never used) by the streams launch's 64-wide chunk loads
 	MF_TRY_HIP(hipMemset(p->rec_csr, 0, ((size_t) p->nnz + 64) * sizeof(mf::StreamRec)));
 	MF_TRY_HIP(hipMemset(p->rec_csc, 0, ((size_t) p->nnz + 64) * sizeof(mf::StreamRec)));
 	{
@@ -570,7 +511,63 @@ int plan_es_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vector
 		MF_TRY_HIP(hipStreamSynchronize(p->stream));
 	}
 	MF_TRY_HIP(raise_lds_limit((const void *) p->sweep.errs, p->es_lds_errors));
-	MF_TRY_HIP(raise_lds_limit((const void *) mf::stream_kernel, mf::kStreamLdsBytes));
+	// ---- LDS-resident streams (mf_resident.hip.h): ~one workgroup per CU; every (side, slice) gets `per` workgroups
+	// of eight waves, and the side's rows are cut into per * 8 runs of consecutive rows balanced by cost
+	{
+		const int sw = p->res_sw, nsl = (p->K + sw - 1) / sw;
+		const int per = std::max(1, ncu / (2 * nsl));
+		std::vector<mf::SliceWg> wgs;
+		for (int side = 0; side < 2; ++side) {
+			const std::vector<int> &pt = side == 0 ? cptr : rptr;
+			const int nrows = side == 0 ? p->items : p->uc;
+			// run boundaries: greedy on cost = entries + 16 per row; a run never splits a row and never holds more than
+			// kResidentRows rows (its row pointers live in one register), so a side of many short rows gets more
+			// workgroups than one per CU and slice
+			std::vector<int> cut(1, 0);
+			{
+				const int target_runs = per * mf::kResidentWaves;
+				const double total_cost = (double) pt[(size_t) nrows] + 16.0 * nrows;
+				double acc_cost = 0, done = 0;
+				int in_run = 0;
+				for (int r = 0; r < nrows; ++r) {
+					acc_cost += (pt[(size_t) r + 1] - pt[(size_t) r]) + 16.0;
+					++in_run;
+					const int left = target_runs - (int) cut.size();
+					const bool share = left > 0 && acc_cost >= (total_cost - done) / (left + 1);
+					if (r + 1 < nrows && (share || in_run == mf::kResidentRows)) {
+						cut.push_back(r + 1);
+						done += acc_cost;
+						acc_cost = 0;
+						in_run = 0;
+					}
+				}
+				cut.push_back(nrows);
+				while (((int) cut.size() - 1) % mf::kResidentWaves != 0) cut.push_back(nrows);
+			}
+			const int nwg_side = ((int) cut.size() - 1) / mf::kResidentWaves;
+			for (int sl = 0; sl < nsl; ++sl)
+				for (int w = 0; w < nwg_side; ++w) {
+					mf::SliceWg g;
+					g.side = side;
+					g.slice = sl;
+					for (int i = 0; i <= mf::kResidentWaves; ++i) {
+						g.row_beg[i] = cut[(size_t) (w * mf::kResidentWaves + i)];
+						g.ent_beg[i] = pt[(size_t) g.row_beg[i]];
+					}
+					if (g.row_beg[mf::kResidentWaves] > g.row_beg[0]) wgs.push_back(g);
+				}
+		}
+		p->res_nwg = (int) wgs.size();
+		p->res_lds = (size_t) std::max(p->uc, p->items) * sw * 8 + mf::kResidentWaves * mf::kResidentWaveLds;
+		if (p->res_nwg > 0) {
+			MF_TRY(dev_alloc(&p->res_wg, wgs.size()));
+			MF_TRY_HIP(hipMemcpy(p->res_wg, wgs.data(), wgs.size() * sizeof(mf::SliceWg), hipMemcpyHostToDevice));
+			const void *fn = sw == 8   ? (const void *) mf::stream_resident_kernel<8>
+			                 : sw == 4 ? (const void *) mf::stream_resident_kernel<4>
+			                           : (const void *) mf::stream_resident_kernel<2>;
+			MF_TRY_HIP(raise_lds_limit(fn, p->res_lds));
+		}
+	}
 	p->es_mode = true;
 	return MF_OK;
 }

@@ -165,8 +165,7 @@ void mf_plan_destroy(mf_plan *p)
 	(void) hipFree(p->es_seg_row);
 	(void) hipFree(p->es_seg_beg);
 	(void) hipFree(p->es_seg_end);
-	(void) hipFree(p->es_tasks);
-	(void) hipFree(p->es_chunks);
+	(void) hipFree(p->res_wg);
 	(void) hipFree(p->csr_ptr);
 	(void) hipFree(p->csr_idx);
 	(void) hipFree(p->csr_val);
@@ -674,11 +673,14 @@ int mf_plan_describe(mf_plan *p, char *buf, int buflen)
 		n = snprintf(buf, (size_t) buflen, "sweep_kernel<KT=%d,KPMAX=%d> K=%d nch=%d stride=%d lds=%zu",
 		             p->sweep.kt, p->sweep.kpmax, p->K, p->nch, p->stride, p->lds_bytes);
 	// how mf_plan_iterate runs an iteration: the two sweeps above, or errors + streams (mf_stream.hip.h)
-	if (n > 0 && n < buflen)
-		snprintf(buf + n, (size_t) (buflen - n),
-		         p->es_mode ? " iterate=errors+streams(segments=%d x<=%d, chunks=%d of %d-piece slices on %d waves, lds=%zu/%zu)"
-		                    : " iterate=sweeps",
-		         p->es_nseg, p->es_nch, p->es_nrows, p->es_sp, p->es_ntasks, p->es_lds_errors, mf::kStreamLdsBytes);
+	if (n > 0 && n < buflen) {
+		if (!p->es_mode)
+			snprintf(buf + n, (size_t) (buflen - n), " iterate=sweeps");
+		else
+			snprintf(buf + n, (size_t) (buflen - n),
+			         " iterate=errors+resident-streams(segments=%d x<=%d, %d-column slices of Y in LDS, %d workgroups, lds=%zu/%zu)",
+			         p->es_nseg, p->es_nch, p->res_sw, p->res_nwg, p->es_lds_errors, p->res_lds);
+	}
 	return MF_OK;
 }
 

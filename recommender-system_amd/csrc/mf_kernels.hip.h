@@ -3,5 +3,6 @@
 #include "mf_common.hip.h"
 #include "mf_sweep.hip.h"
 #include "mf_stream.hip.h"
+#include "mf_resident.hip.h"
 #include "mf_recommend.hip.h"
 #include "mf_collective.hip.h"

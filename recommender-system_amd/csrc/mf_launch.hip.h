@@ -3,6 +3,16 @@
 
 namespace {
 
+// Slice width (columns) of the LDS-resident streams launch, 0 when a slice of the larger factor does not fit the
+// LDS of a CU beside the waves' buffers or K would need more than eight slices (every slice re-reads the records).
+int resident_slice_width(int K, int yrows_max)
+{
+	if (K & 1) return 0;
+	for (int sw : {8, 4, 2})
+		if ((K + sw - 1) / sw <= 8 && (size_t) yrows_max * sw * 8 + mf::kResidentWaves * mf::kResidentWaveLds + 1024 <= kLdsPerCu) return sw;
+	return 0;
+}
+
 int choose_sweep(mf_plan *p)
 {
 	const int K = p->K;
@@ -64,13 +74,15 @@ int choose_sweep(mf_plan *p)
 	// third gather of every entry's row, so it is only chosen while the factors are cache-resident; MF_ITER_MODE=es |
 	// sweeps overrides, MF_ES_MAX_MB moves the limit.
 	p->want_map = false;
-	if (p->sweep.errs && p->nnz > 0 && p->uc < (1 << 24) && p->items < (1 << 24) &&
-	    ((double) p->uc + p->items) * ((K / 2 + 7) / 8) < (double) (1 << 27)) {
+	p->res_sw = resident_slice_width(K, std::max(p->uc, p->items));
+	if (p->sweep.errs && p->nnz > 0) {
+		// Used where the streams launch can keep a slice of Y resident in LDS (mf_resident.hip.h; instML100k 84 -> 39 us
+		// per iteration); MF_ITER_MODE=sweeps keeps the two sweeps, =es asks for it explicitly (same condition).
 		const char *mode = getenv("MF_ITER_MODE");
-		const char *lim = getenv("MF_ES_MAX_MB");
-		const double factor_mb = ((double) p->uc + p->items) * K * 8.0 / 1048576.0;
-		const bool fits = factor_mb <= (lim ? atof(lim) : 48.0);
-		p->want_map = mode ? strcmp(mode, "es") == 0 : fits;
+		// Not below a few thousand entries: there two graph-replayed single-wave sweeps are quicker than a launch that
+		// first copies a slice of Y into every CU's LDS (inst30-40, 170 entries: 17 vs 20 us per iteration).
+		const bool forced = mode && strcmp(mode, "es") == 0;
+		p->want_map = p->res_sw > 0 && !(mode && strcmp(mode, "sweeps") == 0) && (forced || p->nnz >= 4096);
 	}
 	return MF_OK;
 }
@@ -216,21 +228,15 @@ int launch_es_iteration(mf_plan *p)
 	a.err_a = reinterpret_cast<double *>(p->rec_csr);
 	a.err_b = reinterpret_cast<double *>(p->rec_csc);
 	a.map = p->csr2csc;
-	mf::StreamArgs s;
-	s.nwaves = p->es_ntasks;
-	s.K = p->K;
-	s.sp = p->es_sp;
-	s.dbg = getenv("MF_ES_DBG") ? atoi(getenv("MF_ES_DBG")) : 0;
-	s.stamps = nullptr;
-	static unsigned *g_stamps = nullptr;   // timing experiments only
-	if (s.dbg & 64) {
-		if (!g_stamps) MF_HIP(hipMalloc((void **) &g_stamps, (size_t) 4096 * 64 * sizeof(unsigned)));
-		s.stamps = g_stamps;
-	}
-	s.wave_beg = p->es_tasks;
-	s.chunks = p->es_chunks;
-	s.side[0] = mf::StreamSide{p->rec_csc, p->Rbuf[p->cur], p->Lbuf[p->cur], p->Rbuf[nxt]};
-	s.side[1] = mf::StreamSide{p->rec_csr, p->Lbuf[p->cur], p->Rbuf[p->cur], p->Lbuf[nxt]};
+	mf::SliceArgs ra;
+	ra.K = p->K;
+	ra.wg = p->res_wg;
+	ra.ptr[0] = p->csc_ptr;
+	ra.ptr[1] = p->csr_ptr;
+	ra.side[0] = mf::StreamSide{p->rec_csc, p->Rbuf[p->cur], p->Lbuf[p->cur], p->Rbuf[nxt]};
+	ra.side[1] = mf::StreamSide{p->rec_csr, p->Lbuf[p->cur], p->Rbuf[p->cur], p->Lbuf[nxt]};
+	ra.yrows[0] = p->uc;
+	ra.yrows[1] = p->items;
 	TimedLaunch t0{}, t1{};
 	if (p->timing) {
 		MF_HIP(hipEventCreate(&t0.t0));
@@ -244,23 +250,12 @@ int launch_es_iteration(mf_plan *p)
 	MF_HIP(hipLaunchKernel((const void *) p->sweep.errs, dim3(p->es_nseg), dim3(mf::kWave), eargs, p->es_lds_errors,
 	                       p->stream));
 	if (p->timing) MF_HIP(hipEventRecord(t0.t1, p->stream));
-	void *sargs[] = {&s};
-	MF_HIP(hipLaunchKernel((const void *) mf::stream_kernel, dim3(p->es_ntasks), dim3(mf::kWave), sargs,
-	                       mf::kStreamLdsBytes, p->stream));
-	if ((s.dbg & 64) && getenv("MF_ES_STAMPS")) {
-		// dump the stamps of this launch (one line per wave: step deltas), debugging aid only
-		std::vector<unsigned> h((size_t) p->es_ntasks * 64);
-		MF_HIP(hipStreamSynchronize(p->stream));
-		MF_HIP(hipMemcpy(h.data(), g_stamps, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
-		FILE *f = fopen(getenv("MF_ES_STAMPS"), "w");
-		if (f) {
-			for (int w = 0; w < p->es_ntasks; ++w) {
-				fprintf(f, "wave %d:", w);
-				for (int l = 0; l < 64; ++l) fprintf(f, " %u", h[(size_t) w * 64 + l]);
-				fprintf(f, "\n");
-			}
-			fclose(f);
-		}
+	{
+		void *rargs[] = {&ra};
+		const void *fn = p->res_sw == 8   ? (const void *) mf::stream_resident_kernel<8>
+		                 : p->res_sw == 4 ? (const void *) mf::stream_resident_kernel<4>
+		                                  : (const void *) mf::stream_resident_kernel<2>;
+		MF_HIP(hipLaunchKernel(fn, dim3(p->res_nwg), dim3(mf::kResidentThreads), rargs, p->res_lds, p->stream));
 	}
 	if (p->timing) {
 		MF_HIP(hipEventRecord(t1.t1, p->stream));

@@ -116,10 +116,13 @@ struct mf_plan {
 	bool want_map = false, es_mode = false;
 	int *csr2csc = nullptr;
 	mf::StreamRec *rec_csr = nullptr, *rec_csc = nullptr;
-	int es_nseg = 0, es_ntasks = 0, es_nch = 0, es_sp = 0, es_nrows = 0;
+	int es_nseg = 0, es_nch = 0;
 	size_t es_lds_errors = 0;
-	int *es_seg_row = nullptr, *es_seg_beg = nullptr, *es_seg_end = nullptr, *es_tasks = nullptr;
-	mf::StreamChunk *es_chunks = nullptr;
+	int *es_seg_row = nullptr, *es_seg_beg = nullptr, *es_seg_end = nullptr;
+	// streams launch with a column slice of Y resident in LDS (mf_resident.hip.h): small factor matrices only
+	int res_sw = 0, res_nwg = 0;
+	size_t res_lds = 0;
+	mf::SliceWg *res_wg = nullptr;
 
 	double *Lbuf[2] = {nullptr, nullptr};
 	double *Rbuf[2] = {nullptr, nullptr};

@@ -965,20 +965,20 @@ def test_multi_setup_does_not_grow_with_the_shard_count(capi, monkeypatch):
 
 
 # ------------------------------------------------------------------ errors + streams iteration (mf_stream.hip.h)
-@pytest.mark.parametrize("k", [10, 20, 30, 50, 100, 128, 256, 2, 64, 96, 200, 300, 1024])
+@pytest.mark.parametrize("k", [10, 20, 30, 50, 64, 2, 16, 6])
 def test_errors_plus_streams_iteration_bit_exact_for_every_k(capi, orc, k, monkeypatch):
-    """MF_ITER_MODE=es forced: the errors launch (one wave per <= 64-entry segment of a CSR row) + the streams launch
-    (one wave per row of either factor, LDS-DMA rings with hand-counted vmcnt) against the serial oracle, bit for bit.
-    Rows of every kind: empty, one entry, exactly one chunk (the last bundled case), one entry more (the first
-    pipelined case), every chunk count around the ring depths, and rows of up to 18 chunks; every K gives a different
-    number and width of column slices."""
+    """The errors launch (one wave per <= 64-entry segment of a CSR row) + the LDS-resident streams launch (a column
+    slice of all of Y in LDS, a wave per run of consecutive rows) against the serial oracle, bit for bit.  Rows of every
+    kind: empty (leading, trailing, in between), one entry, chunk and step boundaries, rows longer than several
+    chunks; every K gives a different number and width of column slices (8, 4 or 2 columns: K <= 64 / 32 / 16 with
+    the 1100-row factor)."""
     monkeypatch.setenv("MF_ITER_MODE", "es")
     rng = np.random.default_rng(900 + k)
     U, I = 70, 1100
-    nch = 64     # chunk of the streams launch; 5 tile slots: rows of <= 64 entries are bundled five to a wave
-    lens = [0, 1, 2, nch - 1, nch, nch + 1, 2 * nch, 4 * nch - 1, 4 * nch, 4 * nch + 1, 5 * nch, 5 * nch + 1, 7 * nch + 3,
-            9 * nch, 1000, 1100]
-    lens = [min(x, I) for x in lens] + list(rng.integers(0, min(I, 6 * nch + 40), U - len(lens)))
+    nch = 64
+    lens = [0, 0, 1, 2, 7, 8, 9, nch - 1, nch, nch + 1, 2 * nch, 4 * nch - 1, 4 * nch, 4 * nch + 1, 5 * nch, 5 * nch + 1,
+            7 * nch + 3, 0, 9 * nch, 1000, 1100, 0]
+    lens = [min(x, I) for x in lens] + list(rng.integers(0, min(I, 6 * nch + 40), U - len(lens) - 2)) + [0, 0]
     rows, cols = [], []
     for u, m in enumerate(lens):
         c = np.sort(rng.choice(I, int(m), replace=False))
@@ -989,7 +989,7 @@ def test_errors_plus_streams_iteration_bit_exact_for_every_k(capi, orc, k, monke
     d = dict(iters=3, alpha=3e-4, feats=k, users=U, items=I, row=row, col=col,
              val=(rng.random(len(row)) * 4 + 1))
     plan = capi.Plan(U, I, k, d["alpha"], row, col, d["val"])
-    assert "iterate=errors+streams" in plan.describe(), plan.describe()
+    assert "iterate=errors+resident-streams" in plan.describe(), plan.describe()
     L, R = capi.init_factors(U, I, k)
     plan.upload(L, R)
     plan.iterate(3)
@@ -998,6 +998,26 @@ def test_errors_plus_streams_iteration_bit_exact_for_every_k(capi, orc, k, monke
     Lo, Ro, bo = _oracle_run(orc, d)
     assert np.array_equal(Lg, Lo), "L differs"
     assert np.array_equal(Rg, Ro), "R differs"
+
+
+def test_errors_plus_streams_many_short_rows_and_wide_factors(capi, orc, monkeypatch):
+    """More rows than a wave may own (63): a side of thousands of short rows gets extra workgroups; and a factor too
+    large for any resident slice keeps the two sweeps even when the other form is asked for."""
+    monkeypatch.setenv("MF_ITER_MODE", "es")
+    d = random_instance(5, 2200, 300, 10, density=0.01, iters=4, alpha=0.003, empty_rows=tuple(range(40, 120)))
+    plan = capi.Plan(2200, 300, 10, d["alpha"], d["row"], d["col"], d["val"])
+    assert "iterate=errors+resident-streams" in plan.describe(), plan.describe()
+    L, R = capi.init_factors(2200, 300, 10)
+    plan.upload(L, R)
+    plan.iterate(4)
+    Lg, Rg = plan.download()
+    plan.close()
+    Lo, Ro, _ = _oracle_run(orc, d)
+    assert np.array_equal(Lg, Lo) and np.array_equal(Rg, Ro)
+    d2 = random_instance(6, 30000, 40, 10, density=0.05, iters=1)
+    plan = capi.Plan(30000, 40, 10, d2["alpha"], d2["row"], d2["col"], d2["val"])
+    assert "iterate=sweeps" in plan.describe(), plan.describe()
+    plan.close()
 
 
 def test_errors_plus_streams_unsorted_input_and_graph_replay(capi, orc, monkeypatch):
@@ -1027,7 +1047,7 @@ def test_iteration_forms_agree_on_ml100k_and_report_their_timing(capi, monkeypat
     for mode in ("es", "sweeps"):
         monkeypatch.setenv("MF_ITER_MODE", mode)
         plan = capi.Plan(inst.users, inst.items, inst.feats, inst.alpha, inst.row, inst.col, inst.val)
-        assert ("errors+streams" in plan.describe()) == (mode == "es")
+        assert ("iterate=errors+" in plan.describe()) == (mode == "es")
         plan.upload(L0, R0)
         plan.timing(True)
         plan.iterate(40)

@@ -3,7 +3,7 @@
 # usage: gpurun -- bash tools/es_ab.sh   -> gpurun_out/es_ab.txt
 out=gpurun_out/es_ab.txt
 : > $out
-for cfg in "ml100k --steps 3000 --warmup 200" "cfg3 --steps 200 --warmup 20" "cfg3 --skew --steps 200 --warmup 20" "twin --steps 200 --warmup 20"; do
+for cfg in "ml100k --steps 3000 --warmup 200"; do
   for mode in es sweeps; do
     echo "== $cfg MF_ITER_MODE=$mode" >> $out
     MF_ITER_MODE=$mode python bench.py --config $cfg --no-cpu-baseline --no-recommend 2>/dev/null | python -c "
