@@ -2,6 +2,7 @@
  * matfact_host.h -- host-side C helpers around the HIP backend: the pieces of the reference's `main`
  * (matFact.c:61-137) that stay on the CPU.  Plain C, no GPU dependency; libmatfact_host.so.
  *
+ *   mf_host_parse_file_cached  the same behind a binary cache keyed by the file's content
  *   mf_host_parse_file      the `.in` reader          matFact.c:72-110, util.c:12-34 (same grammar, same
  *                                                     error strings, returned instead of die()'d)
  *   mf_host_init_factors    initial L and R           mat2d.c:61-72 + mat2d.c:115-124 (matFact.c:113-120)
@@ -44,6 +45,12 @@ const char *mf_host_parse_strerror(int status);
 int mf_host_parse_file(const char *path, mf_problem *p);
 int mf_host_parse_buffer(const char *text, size_t len, mf_problem *p);
 void mf_host_free_problem(mf_problem *p);
+/* The same through a binary cache (the reference re-parses with fscanf on every run, util.c:30-34):
+ * cache_dir/<content hash>-<size>.mfcache holds the header and the entries as parsed, keyed by the CONTENT of the
+ * `.in` (an edited file never hits a stale cache).  Miss: parse, then write the cache (best effort, write-then-rename).
+ * Hit: the cache file is mapped and p->entries points into the mapping -- no parse, no copy; *cache_hit = 1.
+ * cache_dir NULL or "": plain mf_host_parse_file.  Release with mf_host_free_problem either way. */
+int mf_host_parse_file_cached(const char *path, const char *cache_dir, mf_problem *p, int *cache_hit);
 
 /* glibc-compatible random(): srandom(seed) / random(), TYPE_3 additive feedback, r[i] = r[i-3] + r[i-31] */
 typedef struct mf_rand {

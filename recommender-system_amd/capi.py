@@ -38,6 +38,7 @@ HIP_SYMBOLS = [
 ]
 HOST_SYMBOLS = [
     "mf_host_parse_strerror", "mf_host_parse_file", "mf_host_parse_buffer", "mf_host_free_problem",
+    "mf_host_parse_file_cached",
     "mf_host_srandom", "mf_host_random", "mf_host_init_factors", "mf_host_init_factors_block",
     "mf_host_split_entries", "mf_host_partition_users", "mf_host_balanced_grid", "mf_host_write_out", "mf_host_checkpoint_write",
     "mf_host_checkpoint_read", "mf_host_synth_counts",
@@ -154,6 +155,7 @@ def host():
         lib.mf_host_parse_strerror.restype = C.c_char_p
         lib.mf_host_parse_strerror.argtypes = [C.c_int]
         lib.mf_host_parse_file.argtypes = [C.c_char_p, C.POINTER(Problem)]
+        lib.mf_host_parse_file_cached.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Problem), C.POINTER(C.c_int)]
         lib.mf_host_parse_buffer.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Problem)]
         lib.mf_host_free_problem.argtypes = [C.POINTER(Problem)]
         lib.mf_host_free_problem.restype = None
@@ -214,6 +216,16 @@ def parse_file(path):
     if rc != 0:
         raise ParseError(rc)
     return _from_problem(p)
+
+
+def parse_file_cached(path, cache_dir):
+    """(instance, cache_hit) through the binary cache of mf_host_parse_file_cached."""
+    p = Problem()
+    hit = C.c_int(0)
+    rc = host().mf_host_parse_file_cached(os.fsencode(path), os.fsencode(cache_dir), C.byref(p), C.byref(hit))
+    if rc != 0:
+        raise ParseError(rc)
+    return _from_problem(p), bool(hit.value)
 
 
 def parse_text(text):

@@ -53,6 +53,7 @@ __global__ void __launch_bounds__(256) prep_keys_kernel(const int *__restrict__ 
 	const int r = row[n] - u0, c = col[n];
 	if (r < 0 || r >= uc || c < 0 || c >= items) atomicOr(&flags[0], 1);         // out of range
 	if (n > 0 && row[n - 1] > row[n]) atomicOr(&flags[1], 1);                      // not row-sorted
+	if (n > 0 && row[n - 1] == row[n] && col[n - 1] > col[n]) atomicOr(&flags[2], 1);   // columns not ascending in a row
 	rkey[n] = (unsigned) r;
 	perm[n] = (unsigned) n;
 }
@@ -176,7 +177,7 @@ int build_on_device(mf_plan *p, const mf_shard *s, const mf_entry *aos, bool swa
 	if ((rc = tmp.get(&d_row, nz)) != MF_OK || (rc = tmp.get(&d_col, nz)) != MF_OK ||
 	    (rc = tmp.get(&key_in, nz)) != MF_OK || (rc = tmp.get(&key_out, nz)) != MF_OK ||
 	    (rc = tmp.get(&perm_in, nz)) != MF_OK || (rc = tmp.get(&perm_out, nz)) != MF_OK ||
-	    (rc = tmp.get(&d_flags, 2)) != MF_OK)
+	    (rc = tmp.get(&d_flags, 3)) != MF_OK)
 		return rc;
 	// the values land directly in csr_val when the input is row-sorted (the usual case); otherwise csc_val is
 	// used as the staging copy of the file-order values and overwritten last
@@ -194,10 +195,10 @@ int build_on_device(mf_plan *p, const mf_shard *s, const mf_entry *aos, bool swa
 		MF_HIP(hipMemcpyAsync(d_col, s->col, nz * sizeof(int), hipMemcpyHostToDevice, st));
 		MF_HIP(hipMemcpyAsync(p->csr_val, s->val, nz * sizeof(double), hipMemcpyHostToDevice, st));
 	}
-	MF_HIP(hipMemsetAsync(d_flags, 0, 2 * sizeof(int), st));
+	MF_HIP(hipMemsetAsync(d_flags, 0, 3 * sizeof(int), st));
 	hipLaunchKernelGGL(prep_keys_kernel, dim3(grid), dim3(256), 0, st, d_row, d_col, nnz, p->u0, p->uc, p->items,
 	                   key_in, perm_in, d_flags);
-	int flags[2] = {0, 0};
+	int flags[3] = {0, 0, 0};
 	MF_HIP(hipMemcpyAsync(flags, d_flags, sizeof flags, hipMemcpyDeviceToHost, st));
 	MF_HIP(hipStreamSynchronize(st));
 	if (flags[0]) return MF_ERR_ARGUMENT;
@@ -249,6 +250,22 @@ int build_on_device(mf_plan *p, const mf_shard *s, const mf_entry *aos, bool swa
 	}
 	hipLaunchKernelGGL(ptr_kernel, dim3((unsigned) ((p->items + 256) / 256)), dim3(256), 0, st, key_out, nnz, p->items,
 	                   p->csc_ptr);
+	if (!row_sorted || flags[2]) {
+		// The recommendation masks rated items by walking a user's item ids in ascending order (print_output's cursor,
+		// matFact.c:13-23, relies on (row, col)-sorted input).  The file is not: give the mask its own copy of the ids,
+		// ascending inside every row -- the column-sorted sequence, stably re-sorted by row.  The sweeps keep file order.
+		unsigned *mk_in = nullptr, *mk_out = nullptr, *mv_out = nullptr;
+		if ((rc = tmp.get(&mk_in, nz)) != MF_OK || (rc = tmp.get(&mk_out, nz)) != MF_OK || (rc = tmp.get(&mv_out, nz)) != MF_OK)
+			return rc;
+		MF_HIP(dev_alloc(&p->mask_idx, nz + 64) == MF_OK ? hipSuccess : hipErrorOutOfMemory);
+		hipLaunchKernelGGL(copy_keys_kernel, dim3(grid), dim3(256), 0, st, p->csc_idx, nnz, mk_in, perm_in);
+		size_t need2 = 0;
+		MF_HIP(rocprim::radix_sort_pairs(nullptr, need2, mk_in, mk_out, key_out, mv_out, nz, 0, bits_for(p->uc), st));
+		void *d_temp2 = d_temp;
+		if (need2 > temp_bytes && (rc = tmp.get((char **) &d_temp2, need2)) != MF_OK) return rc;
+		MF_HIP(rocprim::radix_sort_pairs(d_temp2, need2, mk_in, mk_out, key_out, mv_out, nz, 0, bits_for(p->uc), st));
+		MF_HIP(hipMemcpyAsync(p->mask_idx, mv_out, nz * sizeof(int), hipMemcpyDeviceToDevice, st));
+	}
 	if (p->want_map) {
 		MF_HIP(dev_alloc(&p->csr2csc, nz + 64) == MF_OK ? hipSuccess : hipErrorOutOfMemory);
 		hipLaunchKernelGGL(csr2csc_kernel, dim3(grid), dim3(256), 0, st, perm_out, nnz, file2csr, p->csr2csc);
@@ -306,6 +323,18 @@ int build_sparse(mf_plan *p, const mf_shard *s_in, const mf_entry *aos, bool swa
 		MF_TRY(dev_alloc(&p->csr_idx, nz + 64));
 		MF_TRY(dev_alloc(&p->csr_val, nz + 64));
 		MF_TRY_HIP(hipMemcpy(p->csr_ptr, rptr.data(), ((size_t) p->uc + 1) * sizeof(int), hipMemcpyHostToDevice));
+		{
+			// mask ids ascending inside every row (see build_on_device) when the file order is not
+			bool ascending = true;
+			for (int u = 0; u < p->uc && ascending; ++u)
+				ascending = std::is_sorted(idx.begin() + rptr[(size_t) u], idx.begin() + rptr[(size_t) u + 1]);
+			if (!ascending) {
+				std::vector<int> mk(idx);
+				for (int u = 0; u < p->uc; ++u) std::sort(mk.begin() + rptr[(size_t) u], mk.begin() + rptr[(size_t) u + 1]);
+				MF_TRY(dev_alloc(&p->mask_idx, nz + 64));
+				MF_TRY_HIP(hipMemcpy(p->mask_idx, mk.data(), nz * sizeof(int), hipMemcpyHostToDevice));
+			}
+		}
 		if (nz) {
 			MF_TRY_HIP(hipMemcpy(p->csr_idx, idx.data(), nz * sizeof(int), hipMemcpyHostToDevice));
 			MF_TRY_HIP(hipMemcpy(p->csr_val, val.data(), nz * sizeof(double), hipMemcpyHostToDevice));

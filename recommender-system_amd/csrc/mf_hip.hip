@@ -160,6 +160,7 @@ void mf_plan_destroy(mf_plan *p)
 		(void) hipEventDestroy(t.t1);
 	}
 	(void) hipFree(p->csr2csc);
+	(void) hipFree(p->mask_idx);
 	(void) hipFree(p->rec_csr);
 	(void) hipFree(p->rec_csc);
 	(void) hipFree(p->es_seg_row);
@@ -403,7 +404,7 @@ static int launch_recommend_pass1(mf_plan *p, mf_filter *filt)
 	m.L = Lc;
 	m.R = Rc;
 	m.csr_ptr = p->csr_ptr;
-	m.csr_idx = p->csr_idx;
+	m.csr_idx = p->mask_idx ? p->mask_idx : p->csr_idx;
 	m.lnorm = p->lnorm;
 	m.rnorm_max_bits = p->rmax_bits;
 	m.thr_scale = mf_backend_recommend_margin(p->K);
@@ -475,7 +476,7 @@ int mf_plan_recommend(mf_plan *p, int32_t *best)
 	ex.L = p->Lbuf[p->cur];
 	ex.R = p->Rbuf[p->cur];
 	ex.csr_ptr = p->csr_ptr;
-	ex.csr_idx = p->csr_idx;
+	ex.csr_idx = p->mask_idx ? p->mask_idx : p->csr_idx;
 	ex.best = p->best_dev;
 	ex.ulist = nullptr;
 	ex.cand = nullptr;
@@ -524,7 +525,7 @@ int mf_plan_recommend_scored(mf_plan *p, mf_candidate *out)
 	ex.L = p->Lbuf[p->cur];
 	ex.R = p->Rbuf[p->cur];
 	ex.csr_ptr = p->csr_ptr;
-	ex.csr_idx = p->csr_idx;
+	ex.csr_idx = p->mask_idx ? p->mask_idx : p->csr_idx;
 	ex.best = p->best_dev;
 	ex.ulist = nullptr;
 	ex.cand = p->cand_dev;
@@ -555,7 +556,7 @@ int mf_plan_recommend_scored_users(mf_plan *p, const int32_t *users, int32_t n, 
 	ex.L = p->Lbuf[p->cur];
 	ex.R = p->Rbuf[p->cur];
 	ex.csr_ptr = p->csr_ptr;
-	ex.csr_idx = p->csr_idx;
+	ex.csr_idx = p->mask_idx ? p->mask_idx : p->csr_idx;
 	ex.best = p->best_dev;
 	ex.ulist = p->ulist;
 	ex.cand = p->cand_dev;   // written at the user's own index

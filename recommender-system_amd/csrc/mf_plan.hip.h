@@ -111,6 +111,7 @@ struct mf_plan {
 	double *csr_val = nullptr;
 	int *csc_ptr = nullptr, *csc_idx = nullptr;
 	double *csc_val = nullptr;
+	int *mask_idx = nullptr;   // item ids ascending inside every user's row, only when the file order is not (recommend mask)
 	// errors + streams iteration (mf_stream.hip.h): CSR position -> CSC position, the {idx, e_n} records in both orders, the segment table
 	// of the errors launch and the task list (both factors' rows, longest first) of the streams launch
 	bool want_map = false, es_mode = false;

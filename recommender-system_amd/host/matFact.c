@@ -45,21 +45,30 @@ static int mats_state(FILE *f, mf_plan *plan, const mf_problem *p, double *L, do
 
 static int run_with_mats(const char *path, const mf_problem *p, double *L, double *R, int32_t *best, int device)
 {
-	FILE *f = fopen(path, "w");
-	if (!f) return MF_ERR_ARGUMENT;
+	/* the dense A and B of the dump exist only for small instances (mf_plan_predict refuses more than 2^26 elements);
+	 * indices are checked BEFORE A is filled: the parser does not range-check them, only the device build does */
 	const size_t nb = (size_t) p->users * (size_t) p->items;
+	if (p->users < 0 || p->items < 0 || nb > ((size_t) 1 << 26)) return MF_ERR_UNSUPPORTED;
+	for (int64_t n = 0; n < p->nnz; n++)
+		if (p->entries[n].row < 0 || p->entries[n].row >= p->users || p->entries[n].col < 0 ||
+		    p->entries[n].col >= p->items)
+			return MF_ERR_ARGUMENT;
+	int rc = MF_OK;
+	FILE *f = fopen(path, "w");
 	double *B = calloc(nb ? nb : 1, sizeof(double));
 	int32_t *row = malloc(sizeof(int32_t) * (size_t) (p->nnz ? p->nnz : 1));
 	int32_t *col = malloc(sizeof(int32_t) * (size_t) (p->nnz ? p->nnz : 1));
 	double *val = malloc(sizeof(double) * (size_t) (p->nnz ? p->nnz : 1));
-	if (!B || !row || !col || !val) return MF_ERR_NO_MEMORY;
+	mf_plan *plan = NULL;
+	if (!f) rc = MF_ERR_ARGUMENT;
+	if (rc == MF_OK && (!B || !row || !col || !val)) rc = MF_ERR_NO_MEMORY;
+	if (rc != MF_OK) goto done;
 	mf_host_split_entries(p->entries, p->nnz, row, col, val);
 	for (int64_t n = 0; n < p->nnz; n++) B[(size_t) row[n] * p->items + col[n]] = val[n];
 	mats_matrix(f, "Initial matrix A", B, p->users, p->items, 0);
 
 	mf_shard s = {p->users, p->items, p->features, 0, p->users, p->nnz, row, col, val, p->alpha, device, 0, {0, 0}, {0, 0}};
-	mf_plan *plan = NULL;
-	int rc = mf_plan_create(&plan, &s);
+	rc = mf_plan_create(&plan, &s);
 	if (rc == MF_OK) rc = mf_plan_upload_factors(plan, L, R);
 	if (rc == MF_OK) rc = mats_state(f, plan, p, L, R, B, 1);
 	int shown = getenv("MATFACT_MATS_ITERS") ? atoi(getenv("MATFACT_MATS_ITERS")) : 0;
@@ -77,12 +86,13 @@ static int run_with_mats(const char *path, const mf_problem *p, double *L, doubl
 		rc = mats_state(f, plan, p, L, R, B, 0);
 	}
 	if (rc == MF_OK) rc = mf_plan_recommend(plan, best);
+done:   /* the one way out: everything that was acquired is released, whatever failed */
 	mf_plan_destroy(plan);
 	free(B);
 	free(row);
 	free(col);
 	free(val);
-	if (fclose(f) == EOF && rc == MF_OK) rc = MF_ERR_ARGUMENT;
+	if (f && fclose(f) == EOF && rc == MF_OK) rc = MF_ERR_ARGUMENT;
 	return rc;
 }
 
@@ -148,7 +158,10 @@ int main(int argc, char **argv)
 	const double t0 = now();
 
 	mf_problem prob;
-	const int prc = mf_host_parse_file(argv[1], &prob);
+	/* MATFACT_CACHE=<dir>: binary cache of parsed inputs keyed by the file's content (util.c:30-34 re-parses every
+	 * run); unset: the plain parser */
+	int cache_hit = 0;
+	const int prc = mf_host_parse_file_cached(argv[1], getenv("MATFACT_CACHE"), &prob, &cache_hit);
 	if (prc != MF_PARSE_OK) die(mf_host_parse_strerror(prc));
 	const double t1 = now();
 
@@ -197,8 +210,8 @@ int main(int argc, char **argv)
 	fflush(stdout);
 
 	if (getenv("MATFACT_TIMING"))
-		fprintf(stderr, "parse %.6f init %.6f gpu(run) %.6f total %.6f\n", t1 - t0, t2 - t1, t3 - t2,
-		        now() - t0);
+		fprintf(stderr, "parse%s %.6f init %.6f gpu(run) %.6f total %.6f\n", cache_hit ? "(cache)" : "", t1 - t0, t2 - t1,
+		        t3 - t2, now() - t0);
 	free(best);
 	free(L);
 	free(R);

@@ -6,6 +6,10 @@
 #include "../../include/matfact_host.h"
 
 #include <errno.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -271,13 +275,157 @@ int mf_host_parse_file(const char *path, mf_problem *p)
 	return rc;
 }
 
+/* ---- binary cache of parsed `.in` files: the per-token fscanf of util.c:30-34 is the wall-clock floor
+ * of a repeat run once the iterations are on the GPU.  A cache file holds the header and the entries exactly as the
+ * parser produced them (the reference's own 16-byte non_zero_entry structs) under a key made of the CONTENT of the
+ * `.in` (64-bit FNV-1a over 1-MiB blocks, hashed in parallel) and its size, so an edited file can never be served
+ * from a stale cache.  A hit maps the cache file and points mf_problem.entries into the mapping (no copy, no
+ * parse); anything unexpected -- no directory, short file, other magic, other key -- falls back to the parser. */
+typedef struct mf_cache_header {
+	char magic[8];              /* "MFCACHE1" */
+	uint64_t content_hash;
+	uint64_t content_size;
+	int32_t users, items, features, iters;
+	double alpha;
+	int64_t nnz;
+	char pad[8];                /* entries start at byte 64 */
+} mf_cache_header;
+
+#define MF_MAX_MAPPINGS 16
+static struct {
+	void *base;
+	size_t size;
+} g_mappings[MF_MAX_MAPPINGS];
+
+static uint64_t fnv1a64(const unsigned char *p, size_t n)
+{
+	uint64_t h = 1469598103934665603ull;
+	for (size_t i = 0; i < n; ++i) {
+		h ^= p[i];
+		h *= 1099511628211ull;
+	}
+	return h;
+}
+
+static uint64_t content_hash(const unsigned char *p, size_t n)
+{
+	const size_t blk = (size_t) 1 << 20, nblk = (n + blk - 1) / blk;
+	uint64_t *part = malloc(sizeof(uint64_t) * (nblk ? nblk : 1));
+	if (!part) return fnv1a64(p, n);
+	#pragma omp parallel for schedule(static)
+	for (long b = 0; b < (long) nblk; ++b) {
+		const size_t lo = (size_t) b * blk, hi = lo + blk < n ? lo + blk : n;
+		part[b] = fnv1a64(p + lo, hi - lo);
+	}
+	uint64_t h = 1469598103934665603ull ^ (uint64_t) n;
+	for (size_t b = 0; b < nblk; ++b) h = (h ^ part[b]) * 1099511628211ull;
+	free(part);
+	return h;
+}
+
+int mf_host_parse_file_cached(const char *path, const char *cache_dir, mf_problem *p, int *cache_hit)
+{
+	if (cache_hit) *cache_hit = 0;
+	if (!cache_dir || !cache_dir[0]) return mf_host_parse_file(path, p);
+	memset(p, 0, sizeof *p);
+	const int fd = open(path, O_RDONLY);
+	if (fd < 0) return MF_PARSE_OPEN;
+	struct stat st;
+	if (fstat(fd, &st) != 0 || st.st_size <= 0) {
+		close(fd);
+		return mf_host_parse_file(path, p);
+	}
+	const size_t len = (size_t) st.st_size;
+	void *text = mmap(NULL, len, PROT_READ, MAP_PRIVATE, fd, 0);
+	close(fd);
+	if (text == MAP_FAILED) return mf_host_parse_file(path, p);
+	const uint64_t key = content_hash(text, len);
+	char name[4096];
+	snprintf(name, sizeof name, "%s/%016llx-%zu.mfcache", cache_dir, (unsigned long long) key, len);
+
+	/* ---- hit? */
+	const int cfd = open(name, O_RDONLY);
+	if (cfd >= 0) {
+		struct stat cst;
+		mf_cache_header h;
+		int slot = -1;
+		for (int i = 0; i < MF_MAX_MAPPINGS; ++i)
+			if (!g_mappings[i].base) slot = i;
+		if (slot >= 0 && fstat(cfd, &cst) == 0 && (size_t) cst.st_size >= sizeof h &&
+		    pread(cfd, &h, sizeof h, 0) == (ssize_t) sizeof h && memcmp(h.magic, "MFCACHE1", 8) == 0 &&
+		    h.content_hash == key && h.content_size == (uint64_t) len && h.nnz >= 0 && h.users >= 0 && h.items >= 0 &&
+		    (uint64_t) cst.st_size == sizeof h + (uint64_t) h.nnz * sizeof(mf_entry)) {
+			void *map = mmap(NULL, (size_t) cst.st_size, PROT_READ, MAP_PRIVATE, cfd, 0);
+			if (map != MAP_FAILED) {
+				g_mappings[slot].base = map;
+				g_mappings[slot].size = (size_t) cst.st_size;
+				p->users = h.users;
+				p->items = h.items;
+				p->features = h.features;
+				p->iters = h.iters;
+				p->alpha = h.alpha;
+				p->nnz = h.nnz;
+				p->entries = (const mf_entry *) ((const char *) map + sizeof h);
+				close(cfd);
+				munmap(text, len);
+				if (cache_hit) *cache_hit = 1;
+				return MF_PARSE_OK;
+			}
+		}
+		close(cfd);
+	}
+
+	/* ---- miss: parse (the parser wants a NUL behind the text), then write the cache beside a temporary name */
+	char *buf = malloc(len + 1);
+	if (!buf) {
+		munmap(text, len);
+		return MF_PARSE_NOMEM;
+	}
+	memcpy(buf, text, len);
+	buf[len] = '\0';
+	munmap(text, len);
+	const int rc = mf_host_parse_buffer(buf, len, p);
+	free(buf);
+	if (rc != MF_PARSE_OK) return rc;
+	char tmp[4200];
+	snprintf(tmp, sizeof tmp, "%s.%ld.tmp", name, (long) getpid());
+	FILE *out = fopen(tmp, "wb");
+	if (out) {
+		mf_cache_header h;
+		memset(&h, 0, sizeof h);
+		memcpy(h.magic, "MFCACHE1", 8);
+		h.content_hash = key;
+		h.content_size = (uint64_t) len;
+		h.users = p->users;
+		h.items = p->items;
+		h.features = p->features;
+		h.iters = p->iters;
+		h.alpha = p->alpha;
+		h.nnz = p->nnz;
+		const size_t n = (size_t) p->nnz;
+		const int ok = fwrite(&h, sizeof h, 1, out) == 1 && (n == 0 || fwrite(p->entries, sizeof(mf_entry), n, out) == n);
+		if (fclose(out) == 0 && ok)
+			(void) rename(tmp, name);   /* atomic: a reader sees the old state or the whole file */
+		else
+			(void) remove(tmp);
+	}
+	return MF_PARSE_OK;
+}
+
 void mf_host_free_problem(mf_problem *p)
 {
-	if (p) {
-		free((void *) p->entries);
-		p->entries = NULL;
-		p->nnz = 0;
-	}
+	if (!p) return;
+	int mapped = 0;
+	for (int i = 0; i < MF_MAX_MAPPINGS && p->entries; ++i)
+		if (g_mappings[i].base && (const char *) p->entries >= (const char *) g_mappings[i].base &&
+		    (const char *) p->entries < (const char *) g_mappings[i].base + g_mappings[i].size) {
+			munmap(g_mappings[i].base, g_mappings[i].size);
+			g_mappings[i].base = NULL;
+			mapped = 1;
+		}
+	if (!mapped) free((void *) p->entries);
+	p->entries = NULL;
+	p->nnz = 0;
 }
 
 /* ------------------------------------------------------------------------- glibc TYPE_3 random() */

@@ -1057,3 +1057,45 @@ def test_iteration_forms_agree_on_ml100k_and_report_their_timing(capi, monkeypat
         res[mode] = plan.download()
         plan.close()
     assert np.array_equal(res["es"][0], res["sweeps"][0]) and np.array_equal(res["es"][1], res["sweeps"][1])
+
+
+@pytest.mark.parametrize("build", ["device", "host"])
+def test_recommend_masks_rated_items_of_an_unsorted_file(capi, orc, build, monkeypatch):
+    """print_output's cursor (matFact.c:13-23) relies on (row, col)-sorted input; on any other order the
+    reference's cursor sticks and masks nothing afterwards.  The backend masks every rated item whatever the file
+    order (documented deviation): the mask walks its own copy of the item ids, ascending inside every
+    row.  Checked for a fully shuffled file and for one that is row-sorted with shuffled columns; both forms of the
+    recommendation; the answer is the serial program's on the SORTED file."""
+    monkeypatch.setenv("MF_BUILD", build)
+    u, i, k = 300, 420, 24
+    rng = np.random.default_rng(23)
+    L = rng.standard_normal((u, k))
+    R = rng.standard_normal((i, k))
+    d = random_instance(41, u, i, k, density=0.3, full_rows=(5,), empty_rows=(6,))
+    want = orc.recommend(orc.Instance(**d), L, R)
+    order_all = rng.permutation(len(d["row"]))
+    keys = d["row"].astype(np.int64) * (i + 1) + rng.permutation(len(d["row"])) % (i + 1)
+    order_rows = np.lexsort((rng.random(len(d["row"])), d["row"]))     # rows ascending, columns shuffled inside a row
+    for order in (order_all, order_rows):
+        dp = dict(d, row=np.ascontiguousarray(d["row"][order]), col=np.ascontiguousarray(d["col"][order]),
+                  val=np.ascontiguousarray(d["val"][order]))
+        for impl in ("mfma", "exact"):
+            monkeypatch.setenv("MF_RECOMMEND_IMPL", impl)
+            got = capi.backend_recommend(_inst(capi, dp), L, R)
+            assert np.array_equal(got, want), (build, impl)
+
+
+def test_cli_cached_input_prints_the_same_bytes(capi, tmp_path):
+    """MATFACT_CACHE: the first run parses and writes the binary cache, the second maps it; stdout is the
+    reference's .out both times."""
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    name = "inst30-40-10-2-10"
+    want = open(os.path.join(GOLDEN, name + ".out"), "rb").read()
+    for run in range(2):
+        r = subprocess.run([capi.CLI_PATH, golden_in(name)], capture_output=True,
+                           env=dict(os.environ, MATFACT_CACHE=str(cache), MATFACT_TIMING="1"))
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == want
+        assert (b"parse(cache)" in r.stderr) == (run == 1), r.stderr
+    assert len(os.listdir(cache)) == 1

@@ -250,3 +250,54 @@ def test_parallel_init_equals_the_sequential_generator(capi, orc, shape):
     uc = min(uc, u - u0)
     Lb, Rb = capi.init_factors_block(u, i, k, u0, uc)
     assert np.array_equal(Lb, Lo[u0:u0 + uc]) and np.array_equal(Rb, Ro)
+
+
+def test_binary_cache_of_parsed_inputs(capi, tmp_path):
+    """MATFACT_CACHE.  First parse misses and writes <content hash>-<size>.mfcache, the second one maps it
+    (same header, same entries, no parse); the key is the file's CONTENT: an edited file misses; a truncated or foreign
+    cache file is ignored; parse errors are reported as without a cache and leave nothing behind."""
+    import numpy as np
+    d = random_instance(3, 40, 30, 5, density=0.4, iters=7, alpha=0.01, float_ratings=True)
+    src = tmp_path / "a.in"
+    src.write_text(to_text(d))
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    plain = capi.parse_file(str(src))
+    first, hit1 = capi.parse_file_cached(str(src), str(cache))
+    files = sorted(os.listdir(cache))
+    assert not hit1 and len(files) == 1 and files[0].endswith("-%d.mfcache" % src.stat().st_size)
+    second, hit2 = capi.parse_file_cached(str(src), str(cache))
+    assert hit2
+    for inst in (first, second):
+        assert (inst.iters, inst.alpha, inst.feats, inst.users, inst.items) == \
+               (plain.iters, plain.alpha, plain.feats, plain.users, plain.items)
+        assert np.array_equal(inst.row, plain.row) and np.array_equal(inst.col, plain.col)
+        assert np.array_equal(inst.val, plain.val)
+    # an edited file (same length, one digit changed) has another key
+    txt = src.read_text()
+    i = txt.rindex("\n", 0, len(txt) - 1) + 1
+    edited = txt[:i] + txt[i:].replace(txt[i], "9" if txt[i] != "9" else "8", 1)
+    assert len(edited) == len(txt) and edited != txt
+    src.write_text(edited)
+    third, hit3 = capi.parse_file_cached(str(src), str(cache))
+    assert not hit3 and len(os.listdir(cache)) == 2
+    # a damaged cache file is ignored and rewritten
+    src.write_text(txt)
+    victim = os.path.join(str(cache), files[0])
+    with open(victim, "r+b") as f:
+        f.truncate(100)
+    again, hit4 = capi.parse_file_cached(str(src), str(cache))
+    assert not hit4 and np.array_equal(again.val, plain.val)
+    assert capi.parse_file_cached(str(src), str(cache))[1]
+    # errors: same status as the plain parser, no cache file written
+    bad = tmp_path / "bad.in"
+    bad.write_text("3\n0.1\n2\n2 2 1\n0 0 x\n")
+    n = len(os.listdir(cache))
+    with pytest.raises(capi.ParseError) as e:
+        capi.parse_file_cached(str(bad), str(cache))
+    assert str(e.value) == "Error in non-zero entry." and len(os.listdir(cache)) == n
+    with pytest.raises(capi.ParseError):
+        capi.parse_file_cached(str(tmp_path / "missing.in"), str(cache))
+    # no directory: the plain parser, no failure
+    inst, hit = capi.parse_file_cached(str(src), str(tmp_path / "nowhere"))
+    assert not hit and np.array_equal(inst.val, plain.val)
