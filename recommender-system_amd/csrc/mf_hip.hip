@@ -339,8 +339,9 @@ int mf_plan_iterate(mf_plan *p, int iters)
 			const int threads = ((p->uc + p->items + 63) / 64) * 64;
 			void (*rfn)(mf::ResidentArgs) = p->K <= 4    ? mf::sweep_resident_kernel<4>
 			                                : p->K <= 16 ? mf::sweep_resident_kernel<16>
-			                                : p->K <= 32 ? mf::sweep_resident_kernel<32>
-			                                             : mf::sweep_resident_kernel<0>;
+			                                : p->K <= 32 && threads <= mf::resident_max_threads(32)
+			                                    ? mf::sweep_resident_kernel<32>
+			                                    : mf::sweep_resident_kernel<0>;
 			MF_HIP(raise_lds_limit((const void *) rfn, need));
 			hipLaunchKernelGGL(rfn, dim3(1), dim3(threads), need, p->stream, ra);
 			MF_HIP(hipGetLastError());

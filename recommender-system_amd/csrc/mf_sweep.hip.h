@@ -524,8 +524,12 @@ constexpr size_t resident_lds_bytes(int users, int items, int K, long long nnz)
 
 // KMAX > 0: K <= KMAX and the owner keeps its old row and its accumulators in registers (loops fully unrolled, the
 // K loads of a gathered row issued together: one LDS latency per entry instead of one per element); KMAX == 0: any K.
+// The K <= 32 variant keeps three 32-double arrays (192 VGPRs) per thread: that fits the register file only with at
+// most 256 threads per workgroup (512 VGPRs per lane and SIMD / one wave per SIMD), so it is bounded -- and chosen --
+// for users + items <= 256; under a 1024-thread bound it spilled to scratch.
+constexpr int resident_max_threads(int kmax) { return kmax == 32 ? 256 : 1024; }
 template <int KMAX>
-__global__ void __launch_bounds__(1024) sweep_resident_kernel(ResidentArgs a)
+__global__ void __launch_bounds__(resident_max_threads(KMAX)) sweep_resident_kernel(ResidentArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) char rlds[];
 	const int U = a.users, I = a.items, K = a.K, nnz = a.nnz;
