@@ -8,8 +8,9 @@ namespace {
 int resident_slice_width(int K, int yrows_max)
 {
 	if (K & 1) return 0;
-	for (int sw : {8, 4, 2})
-		if ((K + sw - 1) / sw <= 8 && (size_t) yrows_max * sw * 8 + mf::kResidentWaves * mf::kResidentWaveLds + 1024 <= kLdsPerCu) return sw;
+	const char *force = getenv("MF_ES_SW");   // slice width to try first (A/B)
+	for (int sw : {force ? atoi(force) : 8, 8, 4, 2})
+		if ((sw == 8 || sw == 4 || sw == 2) && (K + sw - 1) / sw <= 8 && (size_t) yrows_max * sw * 8 + mf::kResidentWaves * mf::kResidentWaveLds + 1024 <= kLdsPerCu) return sw;
 	return 0;
 }
 

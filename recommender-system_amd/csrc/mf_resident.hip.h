@@ -18,6 +18,7 @@
 // critical path; the products of the next entries are formed beside it.
 #pragma once
 #include "mf_common.hip.h"
+#include <type_traits>
 #include "mf_stream.hip.h"
 
 namespace mf {
@@ -140,7 +141,7 @@ __global__ void __launch_bounds__(kResidentThreads) stream_resident_kernel(Slice
 	close_rows_at(eb);   // leading rows without entries
 	// One chunk of <= 64 records, G entries per step, software-pipelined over the steps: while the products of step s
 	// are being added (the chain of dependent adds), the records of step s+2 and the y values of step s+1 are already
-	// on their way from LDS and the products of step s+1 are written to the other half of `prod`.  A wave's LDS
+	// on their way from LDS and the products of step s+1 are written to the other half of `prod` and read back.  A wave's LDS
 	// accesses execute in program order, so the write of a step's products precedes their reads without a barrier.
 	// Records past the end of the chunk are stored with idx = 0 (a valid row of the slice) and recbuf carries 2 G
 	// records of padding, so the steps need neither clamps nor validity selects; runs of steps that lie inside the
@@ -154,36 +155,59 @@ __global__ void __launch_bounds__(kResidentThreads) stream_resident_kernel(Slice
 		prod[lane] = my1.err * ys[(size_t) my1.idx * SW + c];
 		my1 = recbuf[G + g];                                         // step 1
 		double y1 = ys[(size_t) my1.idx * SW + c];
-		auto step = [&](int sidx, bool inside) {
-			const int s0 = sidx * G;
-			const double *pb = prod + (sidx & 1) * kWave + c;
-			double pr[G];
+		// the products of the step being added are in REGISTERS (pr[PAR]), read back from LDS during the step before:
+		// the chain of dependent adds never waits for LDS.  Two register sets swap roles from step to step.
+		double pr[2][G];
 #pragma unroll
-			for (int u = 0; u < G; ++u) pr[u] = pb[u * SW];
-			const StreamRec my2 = recbuf[s0 + 2 * G + g];            // step s + 2 (padding past the chunk)
+		for (int u = 0; u < G; ++u) pr[0][u] = prod[u * SW + c];
+		int sidx = 0;
+		auto step = [&](auto par_c, bool inside) {
+			constexpr int PAR = decltype(par_c)::value;
+			const int s0 = sidx * G;
+			prod[(PAR ^ 1) * kWave + lane] = my1.err * y1;           // products of step sidx + 1 ...
+			const StreamRec my2 = recbuf[s0 + 2 * G + g];            // records of step sidx + 2 (padding past the chunk)
+			// ... back into registers (every lane group reads them: masking the read-back to the one group that stores
+			// the row was measured 6 % slower -- the LDS cost of an instruction does not shrink with its active lanes)
+#pragma unroll
+			for (int u = 0; u < G; ++u) pr[PAR ^ 1][u] = prod[(PAR ^ 1) * kWave + u * SW + c];
 			if (inside) {
 #pragma unroll
-				for (int u = 0; u < G; ++u) acc = acc + pr[u];
+				for (int u = 0; u < G; ++u) acc = acc + pr[PAR][u];
 			} else {
 				const int m = min(G, cnt - s0), pos0 = c0 + s0;
 #pragma unroll
 				for (int u = 0; u < G; ++u)
 					if (u < m) {
-						acc = acc + pr[u];
+						acc = acc + pr[PAR][u];
 						close_rows_at(pos0 + u + 1);
 					}
 			}
-			prod[((sidx + 1) & 1) * kWave + lane] = my1.err * y1;    // products of step s + 1
 			y1 = ys[(size_t) my2.idx * SW + c];
 			my1 = my2;
 			__builtin_amdgcn_wave_barrier();
+			++sidx;
 		};
-		int sidx = 0;
+		using P0 = std::integral_constant<int, 0>;
+		using P1 = std::integral_constant<int, 1>;
 		while (sidx < nsteps) {
-			// full steps from here that end before the current row does
-			const int nf = min((cnt - sidx * G) / G, (row_end - 1 - (c0 + sidx * G)) / G);
-			for (int k = 0; k < nf; ++k) step(sidx++, true);
-			if (sidx < nsteps) step(sidx++, false);
+			// full steps from here that end before the current row does: no row bookkeeping in their loop
+			int nf = min((cnt - sidx * G) / G, (row_end - 1 - (c0 + sidx * G)) / G);
+			if ((sidx & 1) && nf > 0) {
+				step(P1{}, true);
+				--nf;
+			}
+			if (!(sidx & 1))
+				for (; nf >= 2; nf -= 2) {
+					step(P0{}, true);
+					step(P1{}, true);
+				}
+			if (nf > 0) step(P0{}, true);
+			if (sidx < nsteps) {
+				if (sidx & 1)
+					step(P1{}, false);
+				else
+					step(P0{}, false);
+			}
 		}
 	};
 	// four chunks per trip, each register refilled right after its chunk is consumed: no register is ever copied, so
