@@ -25,7 +25,7 @@ namespace mf {
 
 constexpr int kResidentWaves = 8;
 constexpr int kResidentThreads = kResidentWaves * kWave;
-constexpr int kResidentWaveLds = 3072;    // per wave: 64 + 2 x 32 records (padding of two steps at SW = 2) + 2 x 64 products
+constexpr int kResidentWaveLds = 3584;    // per wave: 64 + 3 x 32 records (padding of three steps at SW = 2) + 2 x 64 products
 constexpr int kResidentRows = 63;          // rows a wave owns at most: its row pointers sit in one register
 constexpr int kResidentCopyPieces = 20;   // 16-byte pieces of the Y slice a thread copies per round (20 x 512 x 16 B = 160 KB)
 
@@ -106,7 +106,8 @@ __global__ void __launch_bounds__(kResidentThreads) stream_resident_kernel(Slice
 			}
 		}
 	}
-	recbuf[64 + lane] = StreamRec{0, 0, 0.0};   // padding behind the chunk (read two steps ahead, never used)
+	recbuf[64 + lane] = StreamRec{0, 0, 0.0};   // padding behind the chunk (read three steps ahead, never used)
+	if (lane < 32) recbuf[128 + lane] = StreamRec{0, 0, 0.0};
 	__syncthreads();
 	if (rb >= re) return;
 
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(kResidentThreads) stream_resident_kernel(Slice
 	// are being added (the chain of dependent adds), the records of step s+2 and the y values of step s+1 are already
 	// on their way from LDS and the products of step s+1 are written to the other half of `prod` and read back.  A wave's LDS
 	// accesses execute in program order, so the write of a step's products precedes their reads without a barrier.
-	// Records past the end of the chunk are stored with idx = 0 (a valid row of the slice) and recbuf carries 2 G
+	// Records past the end of the chunk are stored with idx = 0 (a valid row of the slice) and recbuf carries 3 G
 	// records of padding, so the steps need neither clamps nor validity selects; runs of steps that lie inside the
 	// current row go through a loop without any row bookkeeping.
 	auto process = [&](StreamRec chunk, int c0) {
@@ -155,8 +156,11 @@ __global__ void __launch_bounds__(kResidentThreads) stream_resident_kernel(Slice
 		prod[lane] = my1.err * ys[(size_t) my1.idx * SW + c];
 		my1 = recbuf[G + g];                                         // step 1
 		double y1 = ys[(size_t) my1.idx * SW + c];
+		StreamRec my2 = recbuf[2 * G + g];                           // step 2
 		// the products of the step being added are in REGISTERS (pr[PAR]), read back from LDS during the step before:
-		// the chain of dependent adds never waits for LDS.  Two register sets swap roles from step to step.
+		// the chain of dependent adds never waits for LDS.  Two register sets swap roles from step to step.  Every
+		// LDS result is consumed one full step after its read was issued: records three steps ahead, y values two,
+		// products one.
 		double pr[2][G];
 #pragma unroll
 		for (int u = 0; u < G; ++u) pr[0][u] = prod[u * SW + c];
@@ -164,8 +168,9 @@ __global__ void __launch_bounds__(kResidentThreads) stream_resident_kernel(Slice
 		auto step = [&](auto par_c, bool inside) {
 			constexpr int PAR = decltype(par_c)::value;
 			const int s0 = sidx * G;
+			const StreamRec my3 = recbuf[s0 + 3 * G + g];            // records of step sidx + 3 (padding past the chunk)
+			const double y2 = ys[(size_t) my2.idx * SW + c];         // y of step sidx + 2
 			prod[(PAR ^ 1) * kWave + lane] = my1.err * y1;           // products of step sidx + 1 ...
-			const StreamRec my2 = recbuf[s0 + 2 * G + g];            // records of step sidx + 2 (padding past the chunk)
 			// ... back into registers (every lane group reads them: masking the read-back to the one group that stores
 			// the row was measured 6 % slower -- the LDS cost of an instruction does not shrink with its active lanes)
 #pragma unroll
@@ -182,8 +187,9 @@ __global__ void __launch_bounds__(kResidentThreads) stream_resident_kernel(Slice
 						close_rows_at(pos0 + u + 1);
 					}
 			}
-			y1 = ys[(size_t) my2.idx * SW + c];
 			my1 = my2;
+			y1 = y2;
+			my2 = my3;
 			__builtin_amdgcn_wave_barrier();
 			++sidx;
 		};
