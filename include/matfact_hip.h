@@ -29,10 +29,11 @@
 extern "C" {
 #endif
 
-#define MATFACT_HIP_ABI_VERSION 3   /* 2: mf_shard.users_ext, seeded user sweep, scored recommend (2-D tiles)
+#define MATFACT_HIP_ABI_VERSION 4   /* 2: mf_shard.users_ext, seeded user sweep, scored recommend (2-D tiles)
                                        3: mf_backend_multi_last_timing, MF_MULTI_REDUCE=peer|rccl; the reserved
                                           MF_PLAN_RELAXED_ORDER flag is gone (never implemented: an atomic sum is
-                                          order-nondeterministic and slower than the owner-computes gather) */
+                                          order-nondeterministic and slower than the owner-computes gather)
+                                       4: mf_shard.items_pitch / users_pitch, mf_backend_row_pitch, mf_plan_row_pitch */
 
 /* == non_zero_entry, datatypes.h:10-15: the (user, item, rating) triple, 16 bytes, array-of-structs */
 typedef struct mf_entry {
@@ -122,6 +123,10 @@ typedef struct mf_shard {
 	                            two generations of R, e.g. torch tensors handed to a collective; NULL = own */
 	void *users_ext[2];      /* the same for the two generations of this shard's L block (user_count*features
 	                            doubles each); only a 2-D tile needs them (L summed over the grid row) */
+	int32_t items_pitch;     /* row pitch, in doubles, of the caller-owned items_ext / users_ext buffers: 0 = features */
+	int32_t users_pitch;     /* (rows packed); otherwise even and >= features -- mf_backend_row_pitch(features) is the
+	                            pitch the plan gives its own buffers (rows padded to whole 128-byte lines where that
+	                            saves gathered lines); the buffers then hold rows * pitch doubles */
 } mf_shard;
 
 /* A TILE of the reference's 2-D process grid (matFact-mpi.c:155-214, grid from create_balanced_grid,
@@ -133,6 +138,12 @@ typedef struct mf_shard {
 #define MF_PLAN_DEFAULT 0   /* no flag bits are defined: every sum is formed in the serial order */
 
 int mf_plan_create(mf_plan **out, const mf_shard *shard);
+/* Row pitch (doubles) the plan uses for factor buffers it owns, for this K: features, or features rounded up so that
+ * a row is a whole number of 128-byte lines (a gathered row of 8K bytes otherwise touches a line more than its bytes
+ * wherever it happens to start: 80-byte rows 1.5 lines on average instead of 1).  The pitch of a live plan's L and R
+ * buffers -- what mf_plan_items_next() and friends point at -- is reported by mf_plan_row_pitch. */
+int mf_backend_row_pitch(int features);
+int mf_plan_row_pitch(mf_plan *plan, int32_t *users_pitch, int32_t *items_pitch);
 void mf_plan_destroy(mf_plan *plan);
 
 /* hipStream_t as void*; NULL = the plan's own stream.  All plan work is enqueued on it. */
@@ -153,7 +164,7 @@ int mf_plan_iterate(mf_plan *plan, int iters);
  *   mf_plan_flip: next becomes current                                               */
 int mf_plan_sweep_items(mf_plan *plan, int seed_from_old);
 int mf_plan_sweep_users(mf_plan *plan);
-void *mf_plan_items_next(mf_plan *plan);     /* device pointer, items*features doubles */
+void *mf_plan_items_next(mf_plan *plan);     /* device pointer, items rows of items_pitch doubles */
 void *mf_plan_items_current(mf_plan *plan);
 int mf_plan_flip(mf_plan *plan);
 
@@ -162,7 +173,7 @@ int mf_plan_flip(mf_plan *plan);
  *   mf_plan_sweep_users_seeded: L_next = (seed_from_old ? L_cur : 0) + sum over LOCAL entries  (:188)
  *   caller SUM-all-reduces mf_plan_users_next() over the grid row, mf_plan_items_next() over the grid column. */
 int mf_plan_sweep_users_seeded(mf_plan *plan, int seed_from_old);
-void *mf_plan_users_next(mf_plan *plan);     /* device pointer, user_count*features doubles */
+void *mf_plan_users_next(mf_plan *plan);     /* device pointer, user_count rows of users_pitch doubles */
 void *mf_plan_users_current(mf_plan *plan);
 
 /* Recommendations for this shard's users against the current R; best has user_count entries.

@@ -28,7 +28,7 @@ HIP_SYMBOLS = [
     "mf_backend_strerror", "mf_backend_last_hip_error", "mf_backend_abi_version", "mf_backend_device_count",
     "mf_backend_factorize", "mf_backend_recommend", "mf_backend_run", "mf_backend_run_multi", "mf_backend_run_top1",
     "mf_backend_multi_last_timing",
-    "mf_plan_create", "mf_plan_destroy", "mf_plan_set_stream", "mf_plan_upload_factors",
+    "mf_plan_create", "mf_backend_row_pitch", "mf_plan_row_pitch", "mf_plan_destroy", "mf_plan_set_stream", "mf_plan_upload_factors",
     "mf_plan_download_factors", "mf_plan_iterate", "mf_plan_sweep_items", "mf_plan_sweep_users",
     "mf_plan_items_next", "mf_plan_items_current", "mf_plan_flip", "mf_plan_recommend", "mf_plan_recommend_info",
     "mf_plan_sweep_users_seeded", "mf_plan_users_next", "mf_plan_users_current", "mf_plan_recommend_scored",
@@ -68,7 +68,7 @@ class Shard(C.Structure):  # mf_shard
                 ("user_begin", C.c_int32), ("user_count", C.c_int32), ("nnz", C.c_int64),
                 ("row", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p), ("alpha", C.c_double),
                 ("device", C.c_int32), ("flags", C.c_int32), ("items_ext", C.c_void_p * 2),
-                ("users_ext", C.c_void_p * 2)]
+                ("users_ext", C.c_void_p * 2), ("items_pitch", C.c_int32), ("users_pitch", C.c_int32)]
 
 
 # mf_candidate: the partial scan state of mf_plan_recommend_scored, as a numpy record layout
@@ -111,6 +111,8 @@ def hip():
         lib.mf_backend_factorize.argtypes = [C.POINTER(Problem), _f64p, _f64p, C.c_int]
         lib.mf_backend_recommend.argtypes = [C.POINTER(Problem), _f64p, _f64p, _i32p, C.c_int]
         lib.mf_plan_create.argtypes = [C.POINTER(P), C.POINTER(Shard)]
+        lib.mf_backend_row_pitch.argtypes = [C.c_int]
+        lib.mf_plan_row_pitch.argtypes = [P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         lib.mf_plan_destroy.argtypes = [P]
         lib.mf_plan_destroy.restype = None
         lib.mf_plan_set_stream.argtypes = [P, P]
@@ -276,6 +278,12 @@ def partition_users(users, parts, row_ptr=None):
     return begin
 
 
+def row_pitch(feats):
+    """Row pitch (doubles) the backend gives factor buffers it owns for this K (K, or K padded to whole 128-byte
+    lines); caller-owned buffers may use the same and declare it (Plan(items_pitch=..., users_pitch=...))."""
+    return int(hip().mf_backend_row_pitch(int(feats)))
+
+
 def recommend_margin(feats):
     """8*(K+8)*2^-53: the factor of ||l||*||r|| above which a matrix-core score gap certifies the arg-max."""
     return float(hip().mf_backend_recommend_margin(int(feats)))
@@ -398,7 +406,7 @@ class Plan:
     """mf_plan: one shard resident on one GPU."""
 
     def __init__(self, users_total, items, feats, alpha, row, col, val, user_begin=0, user_count=None,
-                 device=0, items_ext=None, flags=0, users_ext=None):
+                 device=0, items_ext=None, flags=0, users_ext=None, items_pitch=0, users_pitch=0):
         self.users_total, self.items, self.feats = int(users_total), int(items), int(feats)
         self.user_begin = int(user_begin)
         self.user_count = int(users_total - user_begin if user_count is None else user_count)
@@ -414,6 +422,7 @@ class Plan:
             s.items_ext[0], s.items_ext[1] = int(items_ext[0]), int(items_ext[1])
         if users_ext is not None:
             s.users_ext[0], s.users_ext[1] = int(users_ext[0]), int(users_ext[1])
+        s.items_pitch, s.users_pitch = int(items_pitch), int(users_pitch)
         self.nnz = s.nnz
         self._h = C.c_void_p()
         _check(hip().mf_plan_create(C.byref(self._h), C.byref(s)), "mf_plan_create")
@@ -493,6 +502,12 @@ class Plan:
         _check(hip().mf_plan_recommend_filter(self._h, out.ctypes.data, norm, C.byref(rmax)),
                "mf_plan_recommend_filter")
         return out, norm, rmax.value
+
+    def pitches(self):
+        """(users_pitch, items_pitch) of the plan's L and R buffers in doubles."""
+        a, b = C.c_int32(), C.c_int32()
+        _check(hip().mf_plan_row_pitch(self._h, C.byref(a), C.byref(b)), "mf_plan_row_pitch")
+        return a.value, b.value
 
     def recommend_info(self):
         n = C.c_int64()

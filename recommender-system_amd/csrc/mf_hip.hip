@@ -72,6 +72,10 @@ static int plan_create_impl(mf_plan **out, const mf_shard *s, const mf_entry *ao
 	if ((s->users_ext[0] == nullptr) != (s->users_ext[1] == nullptr) || ((uintptr_t) s->users_ext[0] & 15) ||
 	    ((uintptr_t) s->users_ext[1] & 15) || (s->users_ext[0] && s->users_ext[0] == s->users_ext[1]))
 		return MF_ERR_ARGUMENT;
+	// declared pitch of caller-owned buffers: even (16-byte aligned rows) and at least K
+	if (s->items_pitch < 0 || s->users_pitch < 0 || (s->items_pitch && (s->items_pitch < s->features || (s->items_pitch & 1))) ||
+	    (s->users_pitch && (s->users_pitch < s->features || (s->users_pitch & 1))))
+		return MF_ERR_ARGUMENT;
 	const int ndev = mf_backend_device_count();
 	if (ndev <= 0 || s->device < 0 || s->device >= ndev) return MF_ERR_NO_DEVICE;
 	MF_HIP(hipSetDevice(s->device));
@@ -118,7 +122,17 @@ static int plan_create_impl(mf_plan **out, const mf_shard *s, const mf_entry *ao
 		MF_TRY(plan_es_schedule(p, rptr, cptr));
 	}
 
-	const size_t nl = (size_t) p->uc * p->K, nr = (size_t) p->items * p->K;
+	// Row pitch of the factor buffers the plan owns: rows of 8K bytes are gathered in whole 128-byte lines, so when 8K
+	// is not a multiple of 128 a row costs a line more than its bytes wherever it happens to start (80-byte rows:
+	// 1.5 lines on average instead of 1; 240-byte rows: 2.75 instead of 2).  The plan pads its own rows to whole
+	// lines where that saves at least a tenth of the lines; caller-owned buffers keep the caller's pitch K.
+	p->ldl = p->ldr = p->K;
+	{
+		const int own = row_pitch(p->K, p->sweep.dma != 0);
+		p->ldl = s->users_ext[0] && s->users_ext[1] ? (s->users_pitch ? s->users_pitch : p->K) : own;
+		p->ldr = s->items_ext[0] && s->items_ext[1] ? (s->items_pitch ? s->items_pitch : p->K) : own;
+	}
+	const size_t nl = (size_t) p->uc * p->ldl, nr = (size_t) p->items * p->ldr;
 	if (s->users_ext[0] && s->users_ext[1]) {
 		p->l_external = true;
 		p->Lbuf[0] = (double *) s->users_ext[0];
@@ -126,6 +140,10 @@ static int plan_create_impl(mf_plan **out, const mf_shard *s, const mf_entry *ao
 	} else {
 		MF_TRY(dev_alloc(&p->Lbuf[0], nl));
 		MF_TRY(dev_alloc(&p->Lbuf[1], nl));
+		if (p->ldl != p->K) {   // the padding is never read by a kernel, but it is summed by the multi-GPU reducers
+			MF_TRY_HIP(hipMemset(p->Lbuf[0], 0, std::max<size_t>(nl, 1) * sizeof(double)));
+			MF_TRY_HIP(hipMemset(p->Lbuf[1], 0, std::max<size_t>(nl, 1) * sizeof(double)));
+		}
 	}
 	if (s->items_ext[0] && s->items_ext[1]) {
 		p->r_external = true;
@@ -134,6 +152,10 @@ static int plan_create_impl(mf_plan **out, const mf_shard *s, const mf_entry *ao
 	} else {
 		MF_TRY(dev_alloc(&p->Rbuf[0], nr));
 		MF_TRY(dev_alloc(&p->Rbuf[1], nr));
+		if (p->ldr != p->K) {
+			MF_TRY_HIP(hipMemset(p->Rbuf[0], 0, std::max<size_t>(nr, 1) * sizeof(double)));
+			MF_TRY_HIP(hipMemset(p->Rbuf[1], 0, std::max<size_t>(nr, 1) * sizeof(double)));
+		}
 	}
 	MF_TRY(dev_alloc(&p->best_dev, (size_t) p->uc));
 	MF_TRY(dev_alloc(&p->lnorm, (size_t) p->uc));
@@ -149,6 +171,20 @@ static int plan_create_impl(mf_plan **out, const mf_shard *s, const mf_entry *ao
 extern "C" {
 
 int mf_plan_create(mf_plan **out, const mf_shard *s) { return plan_create_impl(out, s, nullptr); }
+
+int mf_backend_row_pitch(int features)
+{
+	if (features < 1) return MF_ERR_ARGUMENT;
+	return row_pitch(features, sweep_is_dma(features));   // rows are padded for the LDS-DMA forms only
+}
+
+int mf_plan_row_pitch(mf_plan *p, int32_t *users_pitch, int32_t *items_pitch)
+{
+	if (!p) return MF_ERR_ARGUMENT;
+	if (users_pitch) *users_pitch = p->ldl;
+	if (items_pitch) *items_pitch = p->ldr;
+	return MF_OK;
+}
 
 void mf_plan_destroy(mf_plan *p)
 {
@@ -220,9 +256,14 @@ int mf_plan_upload_factors(mf_plan *p, const double *L_block, const double *R)
 {
 	if (!p || (!L_block && p->uc > 0) || (!R && p->items > 0)) return MF_ERR_ARGUMENT;
 	MF_HIP(hipSetDevice(p->device));
-	const size_t nl = (size_t) p->uc * p->K * sizeof(double), nr = (size_t) p->items * p->K * sizeof(double);
-	if (nl) MF_HIP(hipMemcpyAsync(p->Lbuf[p->cur], L_block, nl, hipMemcpyHostToDevice, p->stream));
-	if (nr) MF_HIP(hipMemcpyAsync(p->Rbuf[p->cur], R, nr, hipMemcpyHostToDevice, p->stream));
+	// the caller's rows are K doubles apart, the device rows ldl / ldr
+	const size_t w = (size_t) p->K * sizeof(double);
+	if (p->uc)
+		MF_HIP(hipMemcpy2DAsync(p->Lbuf[p->cur], (size_t) p->ldl * sizeof(double), L_block, w, w, (size_t) p->uc,
+		                        hipMemcpyHostToDevice, p->stream));
+	if (p->items)
+		MF_HIP(hipMemcpy2DAsync(p->Rbuf[p->cur], (size_t) p->ldr * sizeof(double), R, w, w, (size_t) p->items,
+		                        hipMemcpyHostToDevice, p->stream));
 	MF_HIP(hipStreamSynchronize(p->stream));
 	p->have_factors = true;
 	return MF_OK;
@@ -233,9 +274,13 @@ int mf_plan_download_factors(mf_plan *p, double *L_block, double *R)
 	if (!p) return MF_ERR_ARGUMENT;
 	if (!p->have_factors) return MF_ERR_STATE;
 	MF_HIP(hipSetDevice(p->device));
-	const size_t nl = (size_t) p->uc * p->K * sizeof(double), nr = (size_t) p->items * p->K * sizeof(double);
-	if (L_block && nl) MF_HIP(hipMemcpyAsync(L_block, p->Lbuf[p->cur], nl, hipMemcpyDeviceToHost, p->stream));
-	if (R && nr) MF_HIP(hipMemcpyAsync(R, p->Rbuf[p->cur], nr, hipMemcpyDeviceToHost, p->stream));
+	const size_t w = (size_t) p->K * sizeof(double);
+	if (L_block && p->uc)
+		MF_HIP(hipMemcpy2DAsync(L_block, w, p->Lbuf[p->cur], (size_t) p->ldl * sizeof(double), w, (size_t) p->uc,
+		                        hipMemcpyDeviceToHost, p->stream));
+	if (R && p->items)
+		MF_HIP(hipMemcpy2DAsync(R, w, p->Rbuf[p->cur], (size_t) p->ldr * sizeof(double), w, (size_t) p->items,
+		                        hipMemcpyDeviceToHost, p->stream));
 	MF_HIP(hipStreamSynchronize(p->stream));
 	return MF_OK;
 }
@@ -321,6 +366,8 @@ int mf_plan_iterate(mf_plan *p, int iters)
 			ra.users = p->uc;
 			ra.items = p->items;
 			ra.K = p->K;
+			ra.ldl = p->ldl;
+			ra.ldr = p->ldr;
 			ra.iters = iters;
 			ra.c2 = p->alpha * 2;
 			ra.csr_ptr = p->csr_ptr;
@@ -394,14 +441,16 @@ static int launch_recommend_pass1(mf_plan *p, mf_filter *filt)
 	MF_HIP(hipMemsetAsync(p->rmax_bits, 0, sizeof(unsigned long long), p->stream));
 	MF_HIP(hipMemsetAsync(p->ucount, 0, sizeof(int), p->stream));
 	hipLaunchKernelGGL(mf::row_norm_kernel, dim3((p->uc + 63) / 64), dim3(64), 0, p->stream, Lc, p->uc,
-	                   p->K, p->lnorm, (unsigned long long *) nullptr);
+	                   p->K, p->ldl, p->lnorm, (unsigned long long *) nullptr);
 	if (p->items > 0)
 		hipLaunchKernelGGL(mf::row_norm_kernel, dim3((p->items + 63) / 64), dim3(64), 0, p->stream, Rc,
-		                   p->items, p->K, (double *) nullptr, p->rmax_bits);
+		                   p->items, p->K, p->ldr, (double *) nullptr, p->rmax_bits);
 	mf::RecMfmaArgs m;
 	m.users = p->uc;
 	m.items = p->items;
 	m.K = p->K;
+	m.ldl = p->ldl;
+	m.ldr = p->ldr;
 	m.L = Lc;
 	m.R = Rc;
 	m.csr_ptr = p->csr_ptr;
@@ -474,6 +523,8 @@ int mf_plan_recommend(mf_plan *p, int32_t *best)
 	ex.users = p->uc;
 	ex.items = p->items;
 	ex.K = p->K;
+	ex.ldl = p->ldl;
+	ex.ldr = p->ldr;
 	ex.L = p->Lbuf[p->cur];
 	ex.R = p->Rbuf[p->cur];
 	ex.csr_ptr = p->csr_ptr;
@@ -523,6 +574,8 @@ int mf_plan_recommend_scored(mf_plan *p, mf_candidate *out)
 	ex.users = p->uc;
 	ex.items = p->items;
 	ex.K = p->K;
+	ex.ldl = p->ldl;
+	ex.ldr = p->ldr;
 	ex.L = p->Lbuf[p->cur];
 	ex.R = p->Rbuf[p->cur];
 	ex.csr_ptr = p->csr_ptr;
@@ -554,6 +607,8 @@ int mf_plan_recommend_scored_users(mf_plan *p, const int32_t *users, int32_t n, 
 	ex.users = n;
 	ex.items = p->items;
 	ex.K = p->K;
+	ex.ldl = p->ldl;
+	ex.ldr = p->ldr;
 	ex.L = p->Lbuf[p->cur];
 	ex.R = p->Rbuf[p->cur];
 	ex.csr_ptr = p->csr_ptr;
@@ -618,7 +673,7 @@ int mf_plan_predict(mf_plan *p, double *B)
 	double *dB = nullptr;
 	MF_HIP(hipMalloc((void **) &dB, n * sizeof(double)));
 	hipLaunchKernelGGL(mf::predict_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, p->stream,
-	                   p->Lbuf[p->cur], p->Rbuf[p->cur], p->uc, p->items, p->K, dB);
+	                   p->Lbuf[p->cur], p->Rbuf[p->cur], p->uc, p->items, p->K, p->ldl, p->ldr, dB);
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = hipMemcpyAsync(B, dB, n * sizeof(double), hipMemcpyDeviceToHost, p->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
@@ -667,8 +722,8 @@ int mf_plan_describe(mf_plan *p, char *buf, int buflen)
 	int n;
 	if (p->sweep.dma)
 		n = snprintf(buf, (size_t) buflen,
-		             "sweep_dma_kernel<KT=%d,NPASS=%d> K=%d nch=%d row_bytes=%d lds=%zu long_rows=%d/%d coop_nch=%d",
-		             p->sweep.kt, p->sweep.kt ? (p->K / 2 + 63) / 64 : p->sweep.kpmax, p->K, p->nch, p->sweep.row_bytes,
+		             "sweep_dma_kernel<KT=%d,NPASS=%d> K=%d pitch=%d/%d nch=%d row_bytes=%d lds=%zu long_rows=%d/%d coop_nch=%d",
+		             p->sweep.kt, p->sweep.kt ? (p->K / 2 + 63) / 64 : p->sweep.kpmax, p->K, p->ldl, p->ldr, p->nch, p->sweep.row_bytes,
 		             p->lds_bytes, p->n_long[0] + (p->coop_all[0] ? p->items : 0), p->n_long[1] + (p->coop_all[1] ? p->uc : 0),
 		             p->coop_all[0] || p->coop_all[1] ? p->nch_coop : 0);
 	else

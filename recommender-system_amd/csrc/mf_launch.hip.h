@@ -14,6 +14,32 @@ int resident_slice_width(int K, int yrows_max)
 	return 0;
 }
 
+// Row pitch (doubles) of a factor buffer the plan owns: 8K bytes rounded up to whole 128-byte lines when that saves
+// at least a tenth of the lines a gathered row touches on average (rows start wherever 8K * r falls: a row of B bytes
+// touches B/128 + 1 - gcd(B, 128)/128 lines).  LDS-DMA forms only; MF_ROW_PITCH=0 keeps K (A/B).
+int row_pitch(int K, bool dma)
+{
+	const char *env = getenv("MF_ROW_PITCH");
+	if (!dma || (env && env[0] == '0')) return K;
+	const int bytes = 8 * K;
+	if (bytes % 128 == 0) return K;
+	int g = 128, b = bytes;
+	while (b) {
+		const int t = g % b;
+		g = b;
+		b = t;
+	}
+	const double plain = bytes / 128.0 + 1.0 - g / 128.0, padded = (bytes + 127) / 128;
+	return plain >= 1.1 * padded ? ((bytes + 127) / 128) * 16 : K;
+}
+
+// does this K run on an LDS-DMA form of the sweep (even K up to 1024, unless MF_SWEEP_IMPL=reg)?  Mirrors choose_sweep.
+bool sweep_is_dma(int K)
+{
+	const char *impl = getenv("MF_SWEEP_IMPL");
+	return !(impl && strcmp(impl, "reg") == 0) && (K & 1) == 0 && K >= 2 && K <= 128 * 8;
+}
+
 int choose_sweep(mf_plan *p)
 {
 	const int K = p->K;
@@ -100,6 +126,8 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 	a.seed = seed;
 	a.c2 = p->alpha * 2;
 	const int nxt = p->cur ^ 1;
+	a.ldx = kind == 0 ? p->ldr : p->ldl;
+	a.ldy = kind == 0 ? p->ldl : p->ldr;
 	if (kind == 0) {   // item sweep: X = R, Y = L, CSC
 		a.nrows = p->items;
 		a.ptr = p->csc_ptr;
@@ -155,6 +183,7 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 		mf::OrderedSumArgs o;
 		o.nrows = p->n_long[kind];
 		o.K = p->K;
+		o.ldx = a.ldx;
 		o.seed = seed;
 		o.nslices = (p->K + mf::kSliceCols - 1) / mf::kSliceCols;
 		o.row = p->long_rows[kind];
@@ -215,6 +244,8 @@ int launch_es_iteration(mf_plan *p)
 	a.K = p->K;
 	a.nch = p->es_nch;
 	a.stride = p->stride;
+	a.ldx = p->ldl;
+	a.ldy = p->ldr;
 	a.seed = 1;
 	a.c2 = p->alpha * 2;
 	a.ptr = p->csr_ptr;
@@ -238,6 +269,10 @@ int launch_es_iteration(mf_plan *p)
 	ra.side[1] = mf::StreamSide{p->rec_csr, p->Lbuf[p->cur], p->Rbuf[p->cur], p->Lbuf[nxt]};
 	ra.yrows[0] = p->uc;
 	ra.yrows[1] = p->items;
+	ra.ldx[0] = p->ldr;   // side 0: X = R, Y = L
+	ra.ldy[0] = p->ldl;
+	ra.ldx[1] = p->ldl;
+	ra.ldy[1] = p->ldr;
 	TimedLaunch t0{}, t1{};
 	if (p->timing) {
 		MF_HIP(hipEventCreate(&t0.t0));

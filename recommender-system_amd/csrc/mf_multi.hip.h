@@ -373,7 +373,8 @@ int mf_backend_run_multi(const mf_problem *pr, double *L, double *R, int32_t *be
 	const double t_setup = now_s();
 	g_multi_timing.setup_s = t_setup - t_start;
 
-	rc = iterate_shards(ss, pr->iters, (size_t) nrows_b * K, use_rccl);
+	// the replicated buffers are summed whole, padding included (every plan pads the same way: zeros)
+	rc = iterate_shards(ss, pr->iters, (size_t) nrows_b * (size_t) ss.plan[0]->ldr, use_rccl);
 	if (rc != MF_OK) return rc;
 	const double t_iter = now_s();
 	g_multi_timing.iterate_s = t_iter - t_setup;

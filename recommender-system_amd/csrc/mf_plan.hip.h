@@ -127,6 +127,7 @@ struct mf_plan {
 
 	double *Lbuf[2] = {nullptr, nullptr};
 	double *Rbuf[2] = {nullptr, nullptr};
+	int ldl = 0, ldr = 0;   // row pitch of the L and R buffers in doubles (K, or K padded to whole 128-byte lines)
 	bool r_external = false;
 	bool l_external = false;
 	bool join_pending = false;          // ordered sums of the last item sweep still run on the side stream

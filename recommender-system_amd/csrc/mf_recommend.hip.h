@@ -16,6 +16,7 @@ struct RecArgs {
 	int users;    // users in this shard
 	int items;
 	int K;
+	int ldl, ldr;                    // row pitch of L and of R in doubles (>= K)
 	const double *__restrict__ L;    // users x K
 	const double *__restrict__ R;    // items x K
 	const int *__restrict__ csr_ptr; // users + 1
@@ -103,8 +104,8 @@ __global__ void __launch_bounds__(256) recommend_kernel(RecArgs a)
 #pragma unroll
 				for (int x = 0; x < 4; ++x) {
 					const int k = kc + sk + x;
-					Ls[sk + x][srow] = (suid >= 0 && k < K) ? a.L[(size_t) suid * K + k] : 0.0;
-					Rs[sk + x][srow] = (ij < a.items && k < K) ? a.R[(size_t) ij * K + k] : 0.0;
+					Ls[sk + x][srow] = (suid >= 0 && k < K) ? a.L[(size_t) suid * a.ldl + k] : 0.0;
+					Rs[sk + x][srow] = (ij < a.items && k < K) ? a.R[(size_t) ij * a.ldr + k] : 0.0;
 				}
 			}
 			__syncthreads();
@@ -185,11 +186,12 @@ __global__ void __launch_bounds__(256) pack_candidates_kernel(const mf_candidate
 // Dense B = L R^T (mat2d_prod, mat2d.c:100-113) for the debug dump of small instances: one thread per
 // (i, j), sequential k from 0.0, separate multiply and add -- every element equals the reference's B[i][j].
 __global__ void __launch_bounds__(256) predict_kernel(const double *__restrict__ L, const double *__restrict__ R,
-                                                      int users, int items, int K, double *__restrict__ B)
+                                                      int users, int items, int K, int ldl, int ldr,
+                                                      double *__restrict__ B)
 {
 	const size_t t = (size_t) blockIdx.x * 256 + threadIdx.x;
 	if (t >= (size_t) users * items) return;
-	const double *l = L + (t / items) * K, *r = R + (t % items) * K;
+	const double *l = L + (t / items) * (size_t) ldl, *r = R + (t % items) * (size_t) ldr;
 	double b = 0.0;
 	for (int k = 0; k < K; ++k) b = b + l[k] * r[k];
 	B[t] = b;
@@ -212,6 +214,7 @@ __global__ void __launch_bounds__(256) predict_kernel(const double *__restrict__
 // ------------------------------------------------------------------------------------------------
 struct RecMfmaArgs {
 	int users, items, K;
+	int ldl, ldr;                              // row pitch of L and of R in doubles (>= K)
 	const double *__restrict__ L;
 	const double *__restrict__ R;
 	const int *__restrict__ csr_ptr;
@@ -225,7 +228,7 @@ struct RecMfmaArgs {
 	mf_filter *__restrict__ filt;              // optional: report (best, second, arg, non-finite) instead of certifying
 };
 
-__global__ void __launch_bounds__(kWave) row_norm_kernel(const double *__restrict__ X, int rows, int K,
+__global__ void __launch_bounds__(kWave) row_norm_kernel(const double *__restrict__ X, int rows, int K, int ld,
                                                           double *__restrict__ norm,
                                                           unsigned long long *__restrict__ max_bits)
 {
@@ -233,7 +236,7 @@ __global__ void __launch_bounds__(kWave) row_norm_kernel(const double *__restric
 	double s = 0.0;
 	if (r < rows)
 		for (int k = 0; k < K; ++k) {
-			const double v = X[(size_t) r * K + k];
+			const double v = X[(size_t) r * ld + k];
 			s += v * v;
 		}
 	s = sqrt(s);
@@ -343,7 +346,7 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 	constexpr int SP = (PC + 3) / 4;
 	const int srow = tid >> 2, sq = tid & 3;
 	const bool a_ok = i0 + srow < a.users;
-	const double *__restrict__ aptr = a.L + (size_t) (a_ok ? i0 + srow : 0) * K;
+	const double *__restrict__ aptr = a.L + (size_t) (a_ok ? i0 + srow : 0) * a.ldl;
 	double2 av[ARES ? 1 : SP], bv[SP];
 
 	auto load2 = [&](const double *__restrict__ rowp, bool ok, int k) {
@@ -359,7 +362,7 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 	// global -> registers for chunk (tile jt, k offset kc); zero outside the matrices
 	auto fetch = [&](int jt, int kc) {
 		const bool b_ok = jt + srow < a.items;
-		const double *__restrict__ bptr = a.R + (size_t) (b_ok ? jt + srow : 0) * K;
+		const double *__restrict__ bptr = a.R + (size_t) (b_ok ? jt + srow : 0) * a.ldr;
 #pragma unroll
 		for (int m = 0; m < SP; ++m) {
 			if (4 * m + 3 >= PC && 4 * m + sq >= PC) continue;   // only the last round of PC % 4 != 0 can be cut
@@ -379,20 +382,20 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 	// LDS-DMA staging of an R chunk: instruction t (t = wave, wave + 8, ...) covers k-pair t/2, rows 64*(t%2)..+63
 	const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 	const unsigned bs_lds = (unsigned) (unsigned long long) (__attribute__((address_space(3))) char *) Bs0;
-	auto dma_image = [&](const double *__restrict__ X, int first_row, int last_row, unsigned lds_base, int kc, int buf) {
+	auto dma_image = [&](const double *__restrict__ X, int ld, int first_row, int last_row, unsigned lds_base, int kc, int buf) {
 #pragma unroll
 		for (int t0 = 0; t0 < 2 * PC; t0 += 8) {
 			const int t = t0 + wave_u;
 			const int pr = t >> 1, rb = (t & 1) * 64, k = kc + 2 * pr;
 			if (t < 2 * PC && k < K) {   // wave-uniform
 				const int row = min(first_row + rb + lane, last_row);   // rows beyond the matrix are masked / never stored
-				const char *g = reinterpret_cast<const char *>(X + (size_t) row * K + k);
+				const char *g = reinterpret_cast<const char *>(X + (size_t) row * ld + k);
 				const unsigned m0 = __builtin_amdgcn_readfirstlane(lds_base + (unsigned) ((buf * kChunkD2 + pr * kMLD2 + rb) * 16));
 				asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0) : "memory");
 			}
 		}
 	};
-	auto dma_chunk = [&](int jt, int kc, int buf) { dma_image(a.R, jt, a.items - 1, bs_lds, kc, buf); };
+	auto dma_chunk = [&](int jt, int kc, int buf) { dma_image(a.R, a.ldr, jt, a.items - 1, bs_lds, kc, buf); };
 	if (BDMA) {
 		// pairs beyond K are never written: zero the staged buffers once so that they hold no NaN patterns
 		for (int sl = tid; sl < 2 * kChunkD2; sl += kMThreads) Bs0[sl] = make_double2(0.0, 0.0);
@@ -404,7 +407,7 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 		for (int sl = tid; sl < kMU * pairs; sl += kMThreads) {
 			const int row = sl / pairs, pr = sl - row * pairs;
 			const bool a_ok = i0 + row < a.users;
-			rec_lds[pr * kMLD2 + row] = load2(a.L + (size_t) (a_ok ? i0 + row : 0) * K, a_ok, 2 * pr);
+			rec_lds[pr * kMLD2 + row] = load2(a.L + (size_t) (a_ok ? i0 + row : 0) * a.ldl, a_ok, 2 * pr);
 		}
 	}
 

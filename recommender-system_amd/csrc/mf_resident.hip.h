@@ -42,6 +42,7 @@ struct SliceArgs {
 	const int *__restrict__ ptr[2];   // row pointers per side (CSC for items, CSR for users)
 	StreamSide side[2];
 	int yrows[2];                     // rows of Y per side
+	int ldx[2], ldy[2];               // row pitch of X and of Y per side, in doubles (>= K)
 };
 
 template <int SW>
@@ -56,6 +57,7 @@ __global__ void __launch_bounds__(kResidentThreads) stream_resident_kernel(Slice
 	const StreamSide sd = a.side[side];
 	const int *__restrict__ ptr = a.ptr[side];
 	const int yrows = a.yrows[side];
+	const size_t ldx = (size_t) a.ldx[side], ldy = (size_t) a.ldy[side];
 	const int col0 = me.slice * SW, ncol = min(SW, K - col0);
 	const double *ys = reinterpret_cast<const double *>(lds);
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,7 +84,7 @@ __global__ void __launch_bounds__(kResidentThreads) stream_resident_kernel(Slice
 	double sv[NSEED];
 #pragma unroll
 	for (int b = 0; b < NSEED; ++b)
-		sv[b] = rb + b * G + g < re ? sd.X_old[(size_t) (rb + b * G + g) * K + col0 + cc] : 0.0;
+		sv[b] = rb + b * G + g < re ? sd.X_old[(size_t) (rb + b * G + g) * ldx + col0 + cc] : 0.0;
 
 	// ---- the slice of every row of Y -> LDS (16-byte pieces, SW/2 per row).  All of a thread's loads are issued
 	// before the first LDS write (one memory latency for the whole copy, not one per piece): at most kPieces per thread.
@@ -97,7 +99,7 @@ __global__ void __launch_bounds__(kResidentThreads) stream_resident_kernel(Slice
 				const int i = base + k * kResidentThreads + tid;
 				const int r = i / PP, pc = i - r * PP;
 				v[k] = make_double2(0.0, 0.0);
-				if (i < total && 2 * pc < ncol) v[k] = *reinterpret_cast<const double2 *>(sd.Y_old + (size_t) r * K + col0 + 2 * pc);
+				if (i < total && 2 * pc < ncol) v[k] = *reinterpret_cast<const double2 *>(sd.Y_old + (size_t) r * ldy + col0 + 2 * pc);
 			}
 #pragma unroll
 			for (int k = 0; k < kResidentCopyPieces; ++k) {
@@ -129,7 +131,7 @@ __global__ void __launch_bounds__(kResidentThreads) stream_resident_kernel(Slice
 	auto close_rows_at = [&](int pos) {   // rows whose last entry is pos - 1 (and empty rows behind them) are complete
 		while (pos == row_end && cur < re) {
 			if (g == 0 && c < ncol) {
-				double *dst = sd.X_new + (size_t) cur * K + col0 + c;
+				double *dst = sd.X_new + (size_t) cur * ldx + col0 + c;
 				asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(acc) : "memory");
 			}
 			++cur;

@@ -34,6 +34,7 @@ struct SweepArgs {
 	int K;
 	int nch;      // entries per chunk (<= 64)
 	int stride;   // LDS row stride in doubles (odd)
+	int ldx, ldy; // row pitch of X and of Y in doubles (>= K: rows of 8K bytes padded to whole 128-byte lines, mf_plan)
 	int seed;     // 1: accumulate onto X_old, 0: onto zero
 	double c2;    // alpha * 2
 	const int *__restrict__ ptr;
@@ -77,7 +78,7 @@ __global__ void __launch_bounds__(kWave) sweep_kernel(SweepArgs a)
 	for (int it = blockIdx.x; it < a.nrows; it += gridDim.x) {
 		const int r = a.rowlist ? a.rowlist[it] : it;
 		const int beg = a.ptr[r], end = a.ptr[r + 1];
-		const double *__restrict__ xrow = a.X_old + (size_t) r * K;
+		const double *__restrict__ xrow = a.X_old + (size_t) r * a.ldx;
 
 		double acc[KPMAX];
 #pragma unroll
@@ -97,7 +98,7 @@ __global__ void __launch_bounds__(kWave) sweep_kernel(SweepArgs a)
 			// ---- stage: gathered rows -> LDS tile (row n of the tile = Y_old[idx_n][:])
 			for (int n = 0; n < cnt; ++n) {
 				const int j = __builtin_amdgcn_readlane(my_idx, n);
-				const double *__restrict__ yrow = a.Y_old + (size_t) j * K;
+				const double *__restrict__ yrow = a.Y_old + (size_t) j * a.ldy;
 				double *trow = tile + n * stride;
 				if ((K & 1) == 0) {
 #pragma unroll 2
@@ -139,7 +140,7 @@ __global__ void __launch_bounds__(kWave) sweep_kernel(SweepArgs a)
 		for (int kk = 0; kk < KPMAX; ++kk) {
 			const int k = lane + kWave * kk;
 			if (k < K)
-				a.X_new[(size_t) r * K + k] = acc[kk];
+				a.X_new[(size_t) r * a.ldx + k] = acc[kk];
 		}
 	}
 }
@@ -205,12 +206,13 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 	const int lane = threadIdx.x;
 	const unsigned voff = (unsigned) lane * 16u;
 	const unsigned long long ybase = (unsigned long long) a.Y_old;
+	const size_t ybytes = (size_t) a.ldy * 8;   // bytes between rows of Y
 
 	for (int it = blockIdx.x; it < a.nrows; it += gridDim.x) {
 		const int r = SEGMENTS ? a.seg_row[it] : (a.rowlist ? a.rowlist[it] : it);
 		const int beg = SEGMENTS ? a.seg_beg[it] : a.ptr[r];
 		const int end = SEGMENTS ? a.seg_end[it] : a.ptr[r + 1];
-		const double2 *__restrict__ xrow2 = reinterpret_cast<const double2 *>(a.X_old + (size_t) r * K);
+		const double2 *__restrict__ xrow2 = reinterpret_cast<const double2 *>(a.X_old + (size_t) r * a.ldx);
 
 		double2 acc[NP];
 #pragma unroll
@@ -252,14 +254,14 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 				for (int n0 = 0; n0 < cnt; n0 += RPI) {
 					const int n = n0 + rr;
 					const int j = __shfl(my_idx, n < cnt ? n : 0);
-					const char *src = reinterpret_cast<const char *>(ybase) + (size_t) (unsigned) j * (size_t) (KT * 8) + 16 * piece;
+					const char *src = reinterpret_cast<const char *>(ybase) + (size_t) (unsigned) j * ybytes + 16 * piece;
 					if (rr < RPI && piece < PP && n < cnt)
 						__builtin_amdgcn_global_load_lds((mf_gvoid *) src, (mf_lvoid *) (tile + n0 * S), 16, 0, 0);
 				}
 			} else
 			for (int n = 0; n < cnt; ++n) {
 				const int j = __builtin_amdgcn_readlane(my_idx, n);
-				unsigned long long base = ybase + (unsigned long long) (unsigned) j * (unsigned long long) (K * 8);
+				unsigned long long base = ybase + (unsigned long long) (unsigned) j * (unsigned long long) ybytes;
 				asm volatile("" : "+s"(base));   // keep the row base scalar
 #pragma unroll
 				for (int p = 0; p < NP; ++p) {
@@ -374,7 +376,7 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 			__syncthreads();   // tile is overwritten by the next chunk's DMA
 		}
 		if (!SEGMENTS) {
-			double2 *__restrict__ out2 = reinterpret_cast<double2 *>(a.X_new + (size_t) r * K);
+			double2 *__restrict__ out2 = reinterpret_cast<double2 *>(a.X_new + (size_t) r * a.ldx);
 #pragma unroll
 			for (int p = 0; p < NP; ++p) {
 				const int q = lane + kWave * p;
@@ -395,6 +397,7 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 // identical sums.
 struct OrderedSumArgs {
 	int nrows, K, seed, nslices;
+	int ldx;                              // row pitch of X in doubles
 	const int *__restrict__ row;          // extreme row ids
 	const long long *__restrict__ sbeg;   // first scratch entry of the row
 	const int *__restrict__ cnt;          // entries of the row
@@ -418,7 +421,7 @@ __global__ void __launch_bounds__(kWave) ordered_sum_kernel(OrderedSumArgs a)
 		const int r = a.row[li], cnt = a.cnt[li];
 		const int k0 = slice * kSliceCols + 2 * (lane & (kSlicePieces - 1));   // this lane's two columns (all lane groups agree)
 		const bool live = k0 < K;                         // K is even: k0 + 1 < K too
-		double2 acc = (a.seed && live) ? *reinterpret_cast<const double2 *>(a.X_old + (size_t) r * K + k0)
+		double2 acc = (a.seed && live) ? *reinterpret_cast<const double2 *>(a.X_old + (size_t) r * a.ldx + k0)
 		                               : make_double2(0.0, 0.0);
 		// block b of the row in this slice: kBlockEntries entries = 1 KiB, lane-linear
 		const char *src = reinterpret_cast<const char *>(
@@ -490,7 +493,7 @@ __global__ void __launch_bounds__(kWave) ordered_sum_kernel(OrderedSumArgs a)
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		for (; b < nblk; ++b) add_block(b, min(EB, cnt - EB * b));
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the ring is reused by the next (row, slice)
-		if (live && lane < kSlicePieces) *reinterpret_cast<double2 *>(a.X_new + (size_t) r * K + k0) = acc;
+		if (live && lane < kSlicePieces) *reinterpret_cast<double2 *>(a.X_new + (size_t) r * a.ldx + k0) = acc;
 	}
 }
 
@@ -503,6 +506,7 @@ __global__ void __launch_bounds__(kWave) ordered_sum_kernel(OrderedSumArgs a)
 // ------------------------------------------------------------------------------------------------
 struct ResidentArgs {
 	int users, items, K, iters;
+	int ldl, ldr;                               // row pitch of L and of R in global memory (doubles)
 	double c2;                                  // alpha * 2
 	const int *__restrict__ csr_ptr;            // users + 1
 	const int *__restrict__ csr_idx;            // item ids
@@ -539,8 +543,8 @@ __global__ void __launch_bounds__(resident_max_threads(KMAX)) sweep_resident_ker
 	int *idx = reinterpret_cast<int *>(val + 2 * (size_t) nnz);   // [csr idx | csc idx]
 	int *ptr = idx + 2 * (size_t) nnz;          // [csr_ptr (U+1) | csc_ptr (I+1)]
 	const int t = threadIdx.x, nt = blockDim.x;
-	for (int x = t; x < U * K; x += nt) gen0[x] = a.L_in[x];
-	for (int x = t; x < I * K; x += nt) gen0[U * K + x] = a.R_in[x];
+	for (int x = t; x < U * K; x += nt) gen0[x] = a.L_in[(size_t) (x / K) * a.ldl + x % K];
+	for (int x = t; x < I * K; x += nt) gen0[U * K + x] = a.R_in[(size_t) (x / K) * a.ldr + x % K];
 	for (int x = t; x < nnz; x += nt) {
 		val[x] = a.csr_val[x];
 		val[nnz + x] = a.csc_val[x];
@@ -602,8 +606,8 @@ __global__ void __launch_bounds__(resident_max_threads(KMAX)) sweep_resident_ker
 		cur = nxt;
 		nxt = sw;
 	}
-	for (int x = t; x < U * K; x += nt) a.L_out[x] = cur[x];
-	for (int x = t; x < I * K; x += nt) a.R_out[x] = cur[U * K + x];
+	for (int x = t; x < U * K; x += nt) a.L_out[(size_t) (x / K) * a.ldl + x % K] = cur[x];
+	for (int x = t; x < I * K; x += nt) a.R_out[(size_t) (x / K) * a.ldr + x % K] = cur[U * K + x];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -624,7 +628,7 @@ template <int KT>
 __global__ void __launch_bounds__(kCoopWaves *kWave) sweep_coop_kernel(SweepArgs a)
 {
 	using G = DmaGeom<KT>;
-	constexpr int K = KT, P = G::kPieces, NP = G::kPasses, S = G::kStride;
+	constexpr int P = G::kPieces, NP = G::kPasses, S = G::kStride;
 	extern __shared__ __attribute__((aligned(16))) char lds[];
 	double2 *xs = reinterpret_cast<double2 *>(lds);
 	const int nch = a.nch;
@@ -638,7 +642,7 @@ __global__ void __launch_bounds__(kCoopWaves *kWave) sweep_coop_kernel(SweepArgs
 	for (int it = blockIdx.x; it < a.nrows; it += gridDim.x) {
 		const int r = a.rowlist ? a.rowlist[it] : it;
 		const int beg = a.ptr[r], end = a.ptr[r + 1];
-		const double2 *__restrict__ xrow2 = reinterpret_cast<const double2 *>(a.X_old + (size_t) r * K);
+		const double2 *__restrict__ xrow2 = reinterpret_cast<const double2 *>(a.X_old + (size_t) r * a.ldx);
 		double2 acc[NP];
 #pragma unroll
 		for (int p = 0; p < NP; ++p) acc[p] = make_double2(0.0, 0.0);
@@ -670,7 +674,7 @@ __global__ void __launch_bounds__(kCoopWaves *kWave) sweep_coop_kernel(SweepArgs
 					}
 					for (int n = 0; n < cnt; ++n) {
 						const int j = __builtin_amdgcn_readlane(my_idx, n);
-						unsigned long long base = ybase + (unsigned long long) (unsigned) j * (unsigned long long) (K * 8);
+						unsigned long long base = ybase + (unsigned long long) (unsigned) j * (unsigned long long) a.ldy * 8ull;
 						asm volatile("" : "+s"(base));
 #pragma unroll
 						for (int p = 0; p < NP; ++p) {
@@ -747,7 +751,7 @@ __global__ void __launch_bounds__(kCoopWaves *kWave) sweep_coop_kernel(SweepArgs
 			__syncthreads();
 		}
 		if (wave == 0) {
-			double2 *__restrict__ out2 = reinterpret_cast<double2 *>(a.X_new + (size_t) r * K);
+			double2 *__restrict__ out2 = reinterpret_cast<double2 *>(a.X_new + (size_t) r * a.ldx);
 #pragma unroll
 			for (int p = 0; p < NP; ++p) {
 				const int q = lane + kWave * p;

@@ -67,7 +67,7 @@ static int run_with_mats(const char *path, const mf_problem *p, double *L, doubl
 	for (int64_t n = 0; n < p->nnz; n++) B[(size_t) row[n] * p->items + col[n]] = val[n];
 	mats_matrix(f, "Initial matrix A", B, p->users, p->items, 0);
 
-	mf_shard s = {p->users, p->items, p->features, 0, p->users, p->nnz, row, col, val, p->alpha, device, 0, {0, 0}, {0, 0}};
+	mf_shard s = {p->users, p->items, p->features, 0, p->users, p->nnz, row, col, val, p->alpha, device, 0, {0, 0}, {0, 0}, 0, 0};
 	rc = mf_plan_create(&plan, &s);
 	if (rc == MF_OK) rc = mf_plan_upload_factors(plan, L, R);
 	if (rc == MF_OK) rc = mats_state(f, plan, p, L, R, B, 1);
@@ -111,7 +111,7 @@ static int run_with_checkpoints(const mf_problem *p, double *L, double *R, int32
 	double *val = malloc(sizeof(double) * (size_t) (p->nnz ? p->nnz : 1));
 	if (!row || !col || !val) return MF_ERR_NO_MEMORY;
 	mf_host_split_entries(p->entries, p->nnz, row, col, val);
-	mf_shard s = {p->users, p->items, p->features, 0, p->users, p->nnz, row, col, val, p->alpha, device, 0, {0, 0}, {0, 0}};
+	mf_shard s = {p->users, p->items, p->features, 0, p->users, p->nnz, row, col, val, p->alpha, device, 0, {0, 0}, {0, 0}, 0, 0};
 	mf_plan *plan = NULL;
 	int rc = mf_plan_create(&plan, &s);
 	if (rc == MF_OK) rc = mf_plan_upload_factors(plan, L, R);

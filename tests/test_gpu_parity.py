@@ -1099,3 +1099,37 @@ def test_cli_cached_input_prints_the_same_bytes(capi, tmp_path):
         assert r.stdout == want
         assert (b"parse(cache)" in r.stderr) == (run == 1), r.stderr
     assert len(os.listdir(cache)) == 1
+
+
+def test_row_pitch_of_own_and_caller_buffers(capi, orc):
+    """128-byte row pitch: the plan pads rows of its own factor buffers to whole 128-byte lines
+    where that saves gathered lines (K=10: 80-byte rows -> pitch 16 doubles, K=30 -> 32; K=20 and K=100 stay packed);
+    caller-owned buffers declare their pitch (mf_shard.items_pitch / users_pitch).  Factors bit-exact for every
+    combination of padded / packed, own / caller-owned, and with the padding switched off."""
+    import torch
+    assert [capi.row_pitch(k) for k in (10, 20, 30, 50, 100, 14, 7)] == [16, 20, 32, 50, 100, 16, 7]
+    for k in (10, 30):
+        d = random_instance(60 + k, 130, 90, k, density=0.3, iters=4, alpha=0.003, empty_rows=(2,), full_rows=(7,))
+        Lo, Ro, bo = _oracle_run(orc, d)
+        ld = capi.row_pitch(k)
+        dev = torch.device("cuda", 0)
+        for own in (True, False):
+            kw = {}
+            if not own:
+                rb = [torch.full((90, ld), float("nan"), dtype=torch.float64, device=dev) for _ in range(2)]
+                lb = [torch.full((130, ld), float("nan"), dtype=torch.float64, device=dev) for _ in range(2)]
+                kw = dict(items_ext=[t.data_ptr() for t in rb], items_pitch=ld,
+                          users_ext=[t.data_ptr() for t in lb], users_pitch=ld)
+            plan = capi.Plan(130, 90, k, d["alpha"], d["row"], d["col"], d["val"], **kw)
+            assert plan.pitches() == (ld, ld)
+            L, R = capi.init_factors(130, 90, k)
+            plan.upload(L, R)
+            plan.iterate(4)
+            Lg, Rg = plan.download()
+            best = plan.recommend()
+            plan.close()
+            assert np.array_equal(Lg, Lo) and np.array_equal(Rg, Ro) and np.array_equal(best, bo), (k, own)
+    # a pitch that is odd or smaller than K is refused
+    with pytest.raises(capi.HipBackendError) as e:
+        capi.Plan(10, 10, 10, 0.1, d["row"][:0], d["col"][:0], d["val"][:0], items_ext=[256, 512], items_pitch=8)
+    assert e.value.status == capi.MF_ERR_ARGUMENT

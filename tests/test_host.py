@@ -26,7 +26,7 @@ def test_libraries_export_every_declared_symbol(capi):
     declared = set(re.findall(r"\b(mf_host_[a-z0-9_]+)\s*\(", hdr)) - {
         "mf_host_block_low", "mf_host_block_high", "mf_host_block_size", "mf_host_block_owner"}
     assert declared == set(capi.HOST_SYMBOLS)
-    assert capi.hip().mf_backend_abi_version() == 3
+    assert capi.hip().mf_backend_abi_version() == 4
 
 
 def test_no_gpu_means_loud_failure_not_fallback(capi):
