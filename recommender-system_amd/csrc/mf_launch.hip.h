@@ -151,7 +151,10 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 	a.scratch = nullptr;
 	a.scratch_entries = 0;
 	if (a.nrows <= 0) return MF_OK;
-	const bool few_rows = a.nrows < 4096;
+	// "few rows": the launch cannot fill the chip whatever the chunk size, its time is the longest row's serial chain
+	// of chunks -> the largest chunk.  Only below ~2048 rows: at 3952 rows (the cfg3 item sweep) the large chunk's LDS
+	// footprint cost more occupancy than it saved (item sweep 0.189 -> 0.123 ms with the ordinary chunk).
+	const bool few_rows = a.nrows < (getenv("MF_SWEEP_FEW") ? atoi(getenv("MF_SWEEP_FEW")) : 2048);
 	const bool coop = p->coop_all[kind];
 	if (few_rows) a.nch = coop ? p->nch_coop : p->nch_few;
 	const size_t lds = coop ? p->lds_bytes_coop : (few_rows ? p->lds_bytes_few : p->lds_bytes);
