@@ -330,15 +330,21 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 		nextcol2 = cur + 1 < cend ? a.csr_idx[cur + 1] : INT32_MAX;
 	}
 
-	// running top-2 of the 8 rows this lane sees: row(tu, r) = 32*wr + 16*tu + lq + 4*r
-	double b1[8], b2[8];
-	int i1[8];
-	unsigned bad = 0;
+	// Running top-2 PER ROW AND ITEM HALF, in LDS (red_b1 / red_b2 / red_i1 / red_bad[row][wc]); a lane only keeps the
+	// runner-up of each of the 8 rows it sees -- row(tu, r) = 32*wr + 16*tu + lq + 4*r -- as the rejection threshold
+	// thr2[x].  (A top-2 per lane cost 41 registers of a kernel that sits at the 256-register limit, and its
+	// thresholds were those of a sixteenth of the row's items each: sixteen times more slow-path visits.)
+	double thr2[8];
 #pragma unroll
-	for (int x = 0; x < 8; ++x) {
-		b1[x] = ninf;
-		b2[x] = ninf;
-		i1[x] = -1;
+	for (int x = 0; x < 8; ++x) thr2[x] = ninf;
+	if (tid < kMU) {
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			red_b1[tid][h] = ninf;
+			red_b2[tid][h] = ninf;
+			red_i1[tid][h] = -1;
+			red_bad[tid][h] = 0;
+		}
 	}
 
 	// staging roles: a chunk image is 128 rows x PC k-pairs of 16 B; thread -> row tid/4, k-pairs 4m + (tid%4)
@@ -411,6 +417,20 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 		}
 	}
 
+	// Can a score of this workgroup be non-finite at all?  |score| <= ||L[i]|| * ||R[j]|| (Cauchy-Schwarz): when the
+	// largest of its 128 user norms times the largest item norm is a finite number well below the overflow threshold,
+	// every partial sum of every score is finite and the arg-max step needs no NaN / inf screening.  A NaN or inf
+	// anywhere in the rows involved makes a norm NaN or inf (compared as bit patterns, a NaN is the largest value).
+	__shared__ unsigned long long lmax_bits[2];
+	if (tid < kMU) {
+		unsigned long long b = i0 + tid < a.users ? (unsigned long long) __double_as_longlong(a.lnorm[i0 + tid]) : 0ull;
+		for (int d = 32; d >= 1; d >>= 1) {
+			const unsigned long long o = __shfl_xor(b, d);
+			b = o > b ? o : b;
+		}
+		if (lane == 0) lmax_bits[wave] = b;
+	}
+
 	int buf = 0;
 	if (BDMA) {
 		dma_chunk(0, 0, 0);
@@ -420,6 +440,12 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 		stage(0);
 	}
 	__syncthreads();
+	bool all_finite;
+	{
+		const unsigned long long lb = lmax_bits[0] > lmax_bits[1] ? lmax_bits[0] : lmax_bits[1];
+		const double bound = __longlong_as_double((long long) lb) * __longlong_as_double((long long) *a.rnorm_max_bits);
+		all_finite = bound <= 1e300;   // false for NaN
+	}
 	for (int j0 = 0; j0 < a.items; j0 += kMI) {
 		mf_d4 acc[2][4];
 #pragma unroll
@@ -503,56 +529,55 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 #pragma unroll
 			for (int r = 0; r < 4; ++r) {
 				const int x = tu * 4 + r;
-				const unsigned long long m = maskw[par][32 * wr + 16 * tu + lq + 4 * r][wc] >> lr;
-				// cheap reject: after the first tiles almost no score beats the row's runner-up
-				bool any = false;
-#pragma unroll
-				for (int ti = 0; ti < 4; ++ti) {
-					const double v = acc[tu][ti][r];
-					any |= !((m >> (16 * ti)) & 1ull) && !(v <= b2[x] && v >= -1.7976931348623157e308);   // v > b2, NaN, +-inf
-				}
+				// cheap reject: after the first tiles almost no score beats the row's runner-up.  One maximum over the
+				// lane's four scores of the row, masks not even looked at: max <= runner-up means no candidate
+				// whatever is rated.  Only when the norms do not rule out non-finite scores (all_finite) a sum is
+				// formed as well: it is non-finite whenever a score is NaN or +-inf (max would drop a NaN; a sum that
+				// merely overflows only costs the slow path).
+				const double v0 = acc[tu][0][r], v1 = acc[tu][1][r], v2 = acc[tu][2][r], v3 = acc[tu][3][r];
+				const double vmax = fmax(fmax(v0, v1), fmax(v2, v3));
+				bool any = !(vmax <= thr2[x]);
+				if (!all_finite) any |= !(fabs((v0 + v1) + (v2 + v3)) <= 1.7976931348623157e308);
 				if (__builtin_amdgcn_ballot_w64(any) != 0) {
+					// slow path (the whole wave, a few dozen times per row over the kernel): the lane's top-2 of the
+					// row among its unrated items, merged over the 16 lanes that share the row, folded into the
+					// row's state in LDS by the first of them, and the new runner-up handed back to all 16
+					const int row = 32 * wr + 16 * tu + lq + 4 * r;
+					const unsigned long long m = maskw[par][row][wc] >> lr;
+					Top2 t{ninf, ninf, -1};
+					int bd = 0;
 #pragma unroll
 					for (int ti = 0; ti < 4; ++ti) {
-						// branch-free insert: b1 starts at -inf, so "first candidate" needs no special case
 						const double v = acc[tu][ti][r];
-						const int j = j0 + 64 * wc + 16 * ti + lr;
 						const bool open = !((m >> (16 * ti)) & 1ull);
 						const bool fin = fabs(v) <= 1.7976931348623157e308;
-						bad |= (unsigned) (open && !fin) << x;
-						const bool use = open && fin;
-						const bool gt1 = use && v > b1[x];
-						const bool gt2 = use && !gt1 && v > b2[x];
-						b2[x] = gt1 ? b1[x] : (gt2 ? v : b2[x]);
-						b1[x] = gt1 ? v : b1[x];
-						i1[x] = gt1 ? j : i1[x];
+						bd |= open && !fin;
+						if (open && fin) top2_merge(t, Top2{v, ninf, j0 + 64 * wc + 16 * ti + lr});
 					}
+#pragma unroll
+					for (int d = 1; d < 16; d <<= 1) {
+						Top2 o;
+						o.b1 = __shfl_xor(t.b1, d, 16);
+						o.b2 = __shfl_xor(t.b2, d, 16);
+						o.i1 = __shfl_xor(t.i1, d, 16);
+						bd |= __shfl_xor(bd, d, 16);
+						top2_merge(t, o);
+					}
+					if (lr == 0) {
+						Top2 st{red_b1[row][wc], red_b2[row][wc], red_i1[row][wc]};
+						top2_merge(st, t);
+						red_b1[row][wc] = st.b1;
+						red_b2[row][wc] = st.b2;
+						red_i1[row][wc] = st.i1;
+						if (bd) red_bad[row][wc] = 1;
+						t.b2 = st.b2;
+					}
+					thr2[x] = __shfl(t.b2, lane & ~15);
 				}
 			}
 	}
 
-	// merge the 16 lanes (lr) that share a row, then the two item halves (wc), then decide
-#pragma unroll
-	for (int x = 0; x < 8; ++x) {
-		Top2 t{b1[x], b2[x], i1[x]};
-		int bd = (bad >> x) & 1;
-#pragma unroll
-		for (int d = 1; d < 16; d <<= 1) {
-			Top2 o;
-			o.b1 = __shfl_xor(t.b1, d, 16);
-			o.b2 = __shfl_xor(t.b2, d, 16);
-			o.i1 = __shfl_xor(t.i1, d, 16);
-			bd |= __shfl_xor(bd, d, 16);
-			top2_merge(t, o);
-		}
-		if (lr == 0) {
-			const int row = 32 * wr + 16 * (x >> 2) + lq + 4 * (x & 3);
-			red_b1[row][wc] = t.b1;
-			red_b2[row][wc] = t.b2;
-			red_i1[row][wc] = t.i1;
-			red_bad[row][wc] = bd;
-		}
-	}
+	// merge the two item halves (wc) of every row, then decide
 	__syncthreads();
 	if (tid < kMU && i0 + tid < a.users) {
 		Top2 t{red_b1[tid][0], red_b2[tid][0], red_i1[tid][0]};
