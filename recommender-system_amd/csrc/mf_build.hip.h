@@ -476,8 +476,22 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 		if (p->coop_all[0] || p->coop_all[1])
 			MF_TRY_HIP(raise_lds_limit((const void *) p->sweep.coop, p->lds_bytes_coop));
 		if (p->n_long[0] || p->n_long[1]) {
-			MF_TRY_HIP(raise_lds_limit((const void *) p->sweep.prod, p->lds_bytes));
-			MF_TRY_HIP(raise_lds_limit((const void *) mf::ordered_sum_kernel, (size_t) mf::kRing * 1024));
+			if (const char *env = getenv("MF_SWEEP_REST"); env && strcmp(env, "coop") == 0 && p->sweep.coop) {
+				p->rest_coop = true;
+				p->nch_coop = getenv("MF_SWEEP_NCH") ? nl : nc;
+				p->lds_bytes_coop = head + (size_t) p->nch_coop * per_entry;
+				MF_TRY_HIP(raise_lds_limit((const void *) p->sweep.coop, p->lds_bytes_coop));
+			}
+			p->nch_prod = p->nch;
+			if (const char *env = getenv("MF_SWEEP_PNCH")) {
+				const int v = atoi(env);
+				if (v >= 1 && v <= 64 && (size_t) p->sweep.xs_bytes + (size_t) v * p->sweep.row_bytes <= kLdsPerCu) p->nch_prod = v;
+			}
+			p->lds_bytes_prod = (size_t) p->sweep.xs_bytes + (size_t) p->nch_prod * p->sweep.row_bytes;
+			p->lds_bytes_osum = (size_t) mf::kRing * 1024;
+			if (const char *env = getenv("MF_OS_LDS")) p->lds_bytes_osum = std::min<size_t>(kLdsPerCu, std::max<size_t>(p->lds_bytes_osum, (size_t) atoll(env)));
+			MF_TRY_HIP(raise_lds_limit((const void *) p->sweep.prod, p->lds_bytes_prod));
+			MF_TRY_HIP(raise_lds_limit((const void *) mf::ordered_sum_kernel, p->lds_bytes_osum));
 			// [slice][entry][kSliceCols doubles]; one block of padding per slice: the last block of a row is read whole
 			p->scratch_entries = (size_t) scratch_entries + mf::kBlockEntries;
 			MF_TRY(dev_alloc(&p->scratch, p->scratch_entries * mf::kSliceCols *

@@ -175,7 +175,7 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 		mf::SweepArgs b = a;
 		b.nrows = p->n_seg[kind];
 		b.rowlist = nullptr;
-		b.nch = p->nch;
+		b.nch = p->nch_prod;
 		b.seg_row = p->seg_row[kind];
 		b.seg_beg = p->seg_beg[kind];
 		b.seg_end = p->seg_end[kind];
@@ -207,19 +207,23 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 			MF_HIP(hipEventRecord(p->ev_fork, p->stream));
 			MF_HIP(hipStreamWaitEvent(p->side_stream, p->ev_fork, 0));
 		}
-		MF_HIP(hipLaunchKernel((const void *) p->sweep.prod, dim3(b.nrows), dim3(mf::kWave), bargs, p->lds_bytes,
+		MF_HIP(hipLaunchKernel((const void *) p->sweep.prod, dim3(b.nrows), dim3(mf::kWave), bargs, p->lds_bytes_prod,
 		                       prod_stream));
 		if (under) {
 			MF_HIP(hipEventRecord(p->ev_fork, p->stream));
 			MF_HIP(hipStreamWaitEvent(p->side_stream, p->ev_fork, 0));
 		}
 		MF_HIP(hipLaunchKernel((const void *) mf::ordered_sum_kernel, dim3(o.nrows * o.nslices), dim3(mf::kWave), oargs,
-		                       (size_t) mf::kRing * 1024, p->side_stream));
+		                       p->lds_bytes_osum, p->side_stream));
 		MF_HIP(hipEventRecord(p->ev_join, p->side_stream));
 		a.nrows = p->n_short[kind];
 		a.rowlist = p->short_rows[kind];
 		a.nch = p->nch;   // the extreme rows are gone: the occupancy-friendly chunk size is right again
-		if (a.nrows > 0)
+		if (a.nrows > 0 && p->rest_coop) {
+			a.nch = p->nch_coop;
+			MF_HIP(hipLaunchKernel((const void *) p->sweep.coop, dim3(std::min(a.nrows, 1 << 20)),
+			                       dim3(mf::kCoopWaves * mf::kWave), args, p->lds_bytes_coop, p->stream));
+		} else if (a.nrows > 0)
 			MF_HIP(hipLaunchKernel((const void *) p->sweep.fn, dim3(std::min(a.nrows, 1 << 20)), dim3(mf::kWave), args,
 			                       p->lds_bytes, p->stream));
 		if (defer_join)

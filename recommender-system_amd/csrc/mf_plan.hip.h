@@ -162,6 +162,10 @@ struct mf_plan {
 	size_t scratch_entries = 0;
 	// tiny sweeps (a few us of data): ONE cooperative launch over all rows; a fork/join costs more than it saves
 	int nch_coop = 0;
+	bool rest_coop = false;     // rows beside the extreme ones go through the cooperative kernel (experiment)
+	int nch_prod = 0;           // chunk size of the products launch (extreme rows)
+	size_t lds_bytes_prod = 0;
+	size_t lds_bytes_osum = 0;  // LDS request of ordered_sum_kernel (ring + padding that bounds the waves per CU)
 	size_t lds_bytes_coop = 0;
 	bool coop_all[2] = {false, false};
 	hipStream_t side_stream = nullptr;
