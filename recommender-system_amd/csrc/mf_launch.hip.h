@@ -196,6 +196,8 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 		o.scratch_entries = p->scratch_entries;
 		o.X_old = a.X_old;
 		o.X_new = a.X_new;
+		o.stamps = nullptr;
+		o.max_cnt = p->max_row_len[kind];
 		void *oargs[] = {&o};
 		// Schedule (MF_SWEEP_SUM_ORDER): "after" (default) -- products kernel and ordered sums on the side stream
 		// while the remaining rows run on the main stream; "under" -- products first on the main stream, then the

@@ -387,113 +387,191 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 }
 
 // Ordered sum of the scaled rows of one extreme row: X_new[r][k] = (...((seed + p_0[k]) + p_1[k]) + ...), the
-// serial accumulation order.  One wave per (row, 16-column slice).  The slice is contiguous over the entries
-// (128 B each), so ONE LDS-DMA instruction brings a block of 8 consecutive entries (1 KiB, lane-linear) into a
-// slot of a 32-slot LDS ring, and the wave keeps 31 blocks -- 248 entries -- in flight ahead of the block it is
-// adding: that hides the ~2 us read latency behind the only true critical path, the chain of dependent adds.
-// The DMA and its s_waitcnt are inline asm with hand-counted vmcnt (hipcc would otherwise wait vmcnt(0) before
-// every LDS read that may alias a pending LDS-DMA); no prefetch registers exist, so nothing can be sunk or
-// spilled.  Every lane (piece = lane & 7) walks the 8 entries of a block in order; the eight lane groups hold
-// identical sums.
+// serial accumulation order.  One wave per (row, 8-column slice).  The slice is contiguous over the entries (64 B
+// each), so ONE LDS-DMA instruction brings a block of 16 consecutive entries (1 KiB) into a slot of an LDS ring and the
+// wave keeps D-1 blocks in flight ahead of the block it is adding: that hides the ~2 us read latency behind the only
+// true critical path, the chain of dependent adds.  The DMA and its s_waitcnt are inline asm with hand-counted vmcnt
+// (hipcc would otherwise wait vmcnt(0) before every LDS read that may alias a pending LDS-DMA); no prefetch registers
+// exist, so nothing can be sunk or spilled.
+//
+// ONE LDS read per block: the DMA's per-lane source address permutes the block so that the lane-linear LDS image is
+// [piece][entry] -- DPP row p (16 lanes) holds piece p of entries 0..15 --, one ds_read_b128 hands every lane ITS
+// entry's two doubles, and the running sum, replicated over the 16 lanes of a row, takes entry e by
+//   v_fmac_f64_dpp acc, v, 1.0  row_newbcast:e          acc <- v[lane e of my row] * 1.0 + acc
+// (gfx90a+ DPP on FP64: row_newbcast only, and only on VOP1/VOP2 encodings -- v_add_f64 is VOP3, v_fmac_f64 is VOP2).
+// The product by 1.0 is exact, so the single rounding is that of the add: the same bits as acc + v.  (The first form had
+// every lane read all 16 entries: 16 ds_read_b128 of 1 KiB per block and wave, 512 LDS cycles per block with four waves
+// on a CU -- 217 ns per block for the longest row of the cfg3 power-law shape against 150 now; tools/micro/osum_probe.)
+//
+// Depth classes: a CU's miss bandwidth (~29 GB/s) is shared by its resident waves in proportion to what each keeps in
+// flight, so a wave streaming the longest row must hold more than the waves of the merely long rows beside it, or it
+// crawls at a quarter of the CU while they finish early.  D = blocks in flight + 1 is picked per row from its length
+// relative to the longest one (R-1, R/2 or R/4 of the R ring slots).
 struct OrderedSumArgs {
 	int nrows, K, seed, nslices;
 	int ldx;                              // row pitch of X in doubles
+	int max_cnt;                          // entries of the longest row of the launch
 	const int *__restrict__ row;          // extreme row ids
 	const long long *__restrict__ sbeg;   // first scratch entry of the row
 	const int *__restrict__ cnt;          // entries of the row
-	const double *__restrict__ scratch;   // [slice][entry][16], each slice padded by 8 entries
+	const double *__restrict__ scratch;   // [slice][entry][kSliceCols], each slice padded by one block
 	size_t scratch_entries;
 	const double *__restrict__ X_old;
 	double *__restrict__ X_new;
+	unsigned long long *stamps;           // probe builds only (tools/micro/osum_probe.hip): 4 clock stamps per task, else null
 };
 
 constexpr int kRing = 32;   // LDS ring slots of 1 KiB (a power of two; kRing-1 <= 63 = the largest vmcnt)
 
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+#define MF_FMAC_BCAST(E)                                                                                              \
+	asm volatile("v_fmac_f64_dpp %0, %2, %4 row_newbcast:" #E " row_mask:0xf bank_mask:0xf\n\t"                        \
+	             "v_fmac_f64_dpp %1, %3, %4 row_newbcast:" #E " row_mask:0xf bank_mask:0xf"                            \
+	             : "+v"(ax), "+v"(ay)                                                                                  \
+	             : "v"(v.x), "v"(v.y), "v"(one))
+
+// One (row, slice) task with D-1 blocks in flight.  `src` = this lane's 16 bytes of block 0 (piece lane >> 4 of entry
+// lane & 15), `my` = its 16 bytes of ring slot 0, `seed_ptr` = its two columns of X_old (null: start from zero).
+template <int D>
+__device__ __forceinline__ void ordered_sum_task(const char *src, unsigned ring_base, unsigned my, int cnt,
+                                                 const double *seed_ptr, double &ax, double &ay, double one,
+                                                 unsigned long long &t_issued)
+{
+	static_assert(D >= 4 && D <= kRing, "depth");
+	constexpr int EB = kBlockEntries;
+	const int nblk = (cnt + EB - 1) / EB;
+	auto issue = [&](int b) {
+		const char *g = src + (size_t) b * 1024;
+		const unsigned m0 = __builtin_amdgcn_readfirstlane(ring_base + (unsigned) (b & (kRing - 1)) * 1024u);
+		asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0) : "memory");   // m0 is a reserved register: hipcc re-loads it before each of its own uses
+	};
+	// asm, so that it stays where it is written (hipcc sinks an ordinary LDS read next to its first use)
+	auto read_block = [&](int b, v2d &v) {
+		const unsigned addr = my + (unsigned) (b & (kRing - 1)) * 1024u;
+		asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+	};
+	auto landed = [&](v2d &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)::"memory"); };
+	auto add16 = [&](const v2d &v) {
+		MF_FMAC_BCAST(0); MF_FMAC_BCAST(1); MF_FMAC_BCAST(2); MF_FMAC_BCAST(3);
+		MF_FMAC_BCAST(4); MF_FMAC_BCAST(5); MF_FMAC_BCAST(6); MF_FMAC_BCAST(7);
+		MF_FMAC_BCAST(8); MF_FMAC_BCAST(9); MF_FMAC_BCAST(10); MF_FMAC_BCAST(11);
+		MF_FMAC_BCAST(12); MF_FMAC_BCAST(13); MF_FMAC_BCAST(14); MF_FMAC_BCAST(15);
+	};
+	auto add_some = [&](const v2d &v, int n) {   // the last, partial block of a row
+		if (n > 0) MF_FMAC_BCAST(0);
+		if (n > 1) MF_FMAC_BCAST(1);
+		if (n > 2) MF_FMAC_BCAST(2);
+		if (n > 3) MF_FMAC_BCAST(3);
+		if (n > 4) MF_FMAC_BCAST(4);
+		if (n > 5) MF_FMAC_BCAST(5);
+		if (n > 6) MF_FMAC_BCAST(6);
+		if (n > 7) MF_FMAC_BCAST(7);
+		if (n > 8) MF_FMAC_BCAST(8);
+		if (n > 9) MF_FMAC_BCAST(9);
+		if (n > 10) MF_FMAC_BCAST(10);
+		if (n > 11) MF_FMAC_BCAST(11);
+		if (n > 12) MF_FMAC_BCAST(12);
+		if (n > 13) MF_FMAC_BCAST(13);
+		if (n > 14) MF_FMAC_BCAST(14);
+		if (n > 15) MF_FMAC_BCAST(15);
+	};
+	// Hand-counted region.  The seed is loaded from asm as well and BEFORE the blocks: loads return in order, so it has
+	// landed whenever block 0 has, and its round trip runs beside theirs instead of in front of them.
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing older in flight (the store of a previous task)
+	v2d seedv = {0.0, 0.0};
+	if (seed_ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(seedv) : "v"(seed_ptr) : "memory");
+	const int ahead = min(nblk, D - 1);
+	for (int b = 0; b < ahead; ++b) issue(b);
+	t_issued = __builtin_amdgcn_s_memrealtime();   // (probe) no store inside the hand-counted region
+	int b = 0;
+	// Steady state: the read of block b+1 is in flight under the 16 dependent adds of block b (the true critical path).
+	// D-1 blocks are issued beyond b-1, so block b+1 has landed once at most D-3 newer DMAs are outstanding; the slot
+	// refilled after the adds of block b is free: its last reader was block b+D-1-kRing <= b-1, read two steps ago.
+	if (nblk > D - 1) {   // at least one block is still to be issued
+		v2d cur, nxt;
+		asm volatile("s_waitcnt vmcnt(%1)" : "+v"(seedv) : "n"(D - 2) : "memory");
+		ax = seedv.x;
+		ay = seedv.y;
+		read_block(0, cur);
+		auto step = [&](int blk, v2d &have, v2d &want) {
+			landed(have);
+			asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 3) : "memory");
+			read_block(blk + 1, want);
+			add16(have);
+			issue(blk + D - 1);
+		};
+		for (; b + D < nblk; b += 2) {   // two blocks per trip: the two registers swap roles, no copies
+			step(b, cur, nxt);
+			step(b + 1, nxt, cur);
+		}
+		if (b + (D - 1) < nblk) {
+			step(b, cur, nxt);
+			cur = nxt;
+			++b;
+		}
+		// `cur` holds block b (a full one: b + D - 1 == nblk here), not yet added
+		landed(cur);
+		add16(cur);
+		++b;
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	} else {
+		asm volatile("s_waitcnt vmcnt(0)" : "+v"(seedv)::"memory");
+		ax = seedv.x;
+		ay = seedv.y;
+	}
+	for (; b < nblk; ++b) {
+		v2d v;
+		read_block(b, v);
+		landed(v);
+		const int n = min(EB, cnt - EB * b);
+		if (n == EB)
+			add16(v);
+		else
+			add_some(v, n);
+	}
+}
+#undef MF_FMAC_BCAST
+
 __global__ void __launch_bounds__(kWave) ordered_sum_kernel(OrderedSumArgs a)
 {
+	static_assert(kSliceCols == 8, "row p of the wave = piece p of the slice: four pieces");
 	extern __shared__ __attribute__((aligned(1024))) char ring[];   // kRing * 1024 bytes
 	const int lane = threadIdx.x, K = a.K;
 	const unsigned ring_base = (unsigned) (unsigned long long) (__attribute__((address_space(3))) char *) ring;
-	const char *my = ring + 16 * (lane & (kSlicePieces - 1));   // this lane's piece inside an entry
+	const int piece = lane >> 4, ent = lane & 15;
+	const unsigned my = ring_base + 16u * (unsigned) lane;
 	const int total = a.nrows * a.nslices;
+	double one = 1.0;
+	asm volatile("" : "+v"(one));   // a register operand (VOP2 src1), not a literal
 	for (int it = blockIdx.x; it < total; it += gridDim.x) {
 		const int li = it / a.nslices, slice = it % a.nslices;
 		const int r = a.row[li], cnt = a.cnt[li];
-		const int k0 = slice * kSliceCols + 2 * (lane & (kSlicePieces - 1));   // this lane's two columns (all lane groups agree)
-		const bool live = k0 < K;                         // K is even: k0 + 1 < K too
-		double2 acc = (a.seed && live) ? *reinterpret_cast<const double2 *>(a.X_old + (size_t) r * a.ldx + k0)
-		                               : make_double2(0.0, 0.0);
-		// block b of the row in this slice: kBlockEntries entries = 1 KiB, lane-linear
+		unsigned long long *stamp = (a.stamps && lane == 0) ? a.stamps + 4 * (size_t) it : nullptr;
+		const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+		unsigned long long t_issued = 0;
+		const int k0 = slice * kSliceCols + 2 * piece;   // this row-of-lanes' two columns
+		const bool live = k0 < K;                        // K is even: k0 + 1 < K too
+		// block b of the row in this slice: 16 entries of 64 B; this lane fetches piece `piece` of entry `ent`
 		const char *src = reinterpret_cast<const char *>(
 		                      a.scratch + (((size_t) slice * a.scratch_entries + (size_t) a.sbeg[li]) << kSliceShift)) +
-		                  16 * lane;
-		constexpr int EB = kBlockEntries, EBYTES = kSliceCols * 8;
-		const int nblk = (cnt + EB - 1) / EB;
-
-		// every ordinary load above must have landed before the hand-counted region starts
-		asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-		auto issue = [&](int b) {
-			const char *g = src + (size_t) b * 1024;
-			const unsigned m0 = __builtin_amdgcn_readfirstlane(ring_base + (unsigned) (b & (kRing - 1)) * 1024u);
-			asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0) : "memory");   // m0 is a reserved register: hipcc re-loads it before each of its own uses
-		};
-		auto read_block = [&](int b, double2 (&v)[EB]) {
-			const char *slot = my + (b & (kRing - 1)) * 1024;
-#pragma unroll
-			for (int e = 0; e < EB; ++e) v[e] = *reinterpret_cast<const double2 *>(slot + EBYTES * e);
-		};
-		auto add_regs = [&](const double2 (&v)[EB]) {
-#pragma unroll
-			for (int e = 0; e < EB; ++e) {
-				acc.x = acc.x + v[e].x;
-				acc.y = acc.y + v[e].y;
-			}
-		};
-		auto add_block = [&](int b, int entries) {
-			const char *slot = my + (b & (kRing - 1)) * 1024;
-			for (int e = 0; e < entries; ++e) {
-				const double2 v = *reinterpret_cast<const double2 *>(slot + EBYTES * e);
-				acc.x = acc.x + v.x;
-				acc.y = acc.y + v.y;
-			}
-		};
-		const int ahead = min(nblk, kRing - 1);
-		for (int b = 0; b < ahead; ++b) issue(b);
-		int b = 0;
-		// Steady state, software-pipelined by one block: while the dependent adds of block b run (the only true
-		// critical path), the LDS reads of block b+1 are already in flight.  kRing-1 blocks are issued beyond b-1,
-		// so block b+1 has landed once at most kRing-3 newer DMAs are outstanding; the slot refilled after the adds
-		// of block b is that of block b-1, whose values were consumed an iteration ago.
-		if (nblk > kRing - 1) {   // at least one block is still to be issued
-			double2 cur[EB], nxt[EB];
-			asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRing - 2) : "memory");
-			read_block(0, cur);
-			auto step = [&](int blk, const double2 (&have)[EB], double2 (&want)[EB]) {
-				asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRing - 3) : "memory");
-				read_block(blk + 1, want);
-				add_regs(have);
-				// no lgkmcnt wait here: the slot refilled now is that of block blk-1, whose ds_reads were issued
-				// two steps ago (LDS serves a wave's instructions in order, and the DMA data arrive ~us later)
-				issue(blk + kRing - 1);
-			};
-			for (; b + kRing < nblk; b += 2) {   // two blocks per trip: the two register sets swap roles, no copies
-				step(b, cur, nxt);
-				step(b + 1, nxt, cur);
-			}
-			if (b + (kRing - 1) < nblk) {
-				step(b, cur, nxt);
-#pragma unroll
-				for (int e = 0; e < EB; ++e) cur[e] = nxt[e];
-				++b;
-			}
-			// `cur` holds block b (a full one: b + kRing - 1 == nblk here), not yet added
-			add_regs(cur);
-			++b;
+		                  64 * ent + 16 * piece;
+		const double *seed_ptr = (a.seed && live) ? a.X_old + (size_t) r * a.ldx + k0 : nullptr;
+		double ax = 0.0, ay = 0.0;
+		// in flight: all of the ring for the longest rows, a half or a quarter of it for the shorter ones
+		if (4 * (long long) cnt >= 2 * (long long) a.max_cnt)
+			ordered_sum_task<kRing>(src, ring_base, my, cnt, seed_ptr, ax, ay, one, t_issued);
+		else if (4 * (long long) cnt >= (long long) a.max_cnt)
+			ordered_sum_task<kRing / 2>(src, ring_base, my, cnt, seed_ptr, ax, ay, one, t_issued);
+		else
+			ordered_sum_task<kRing / 4>(src, ring_base, my, cnt, seed_ptr, ax, ay, one, t_issued);
+		if (live && ent == 0) *reinterpret_cast<double2 *>(a.X_new + (size_t) r * a.ldx + k0) = make_double2(ax, ay);
+		if (stamp) {
+			stamp[0] = t_start;
+			stamp[1] = t_issued;
+			stamp[2] = __builtin_amdgcn_s_memrealtime();
+			stamp[3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
 		}
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		for (; b < nblk; ++b) add_block(b, min(EB, cnt - EB * b));
-		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the ring is reused by the next (row, slice)
-		if (live && lane < kSlicePieces) *reinterpret_cast<double2 *>(a.X_new + (size_t) r * a.ldx + k0) = acc;
 	}
 }
 

@@ -3,9 +3,11 @@
 // launch costs when nothing else runs beside it, over the LDS request (waves per CU) and the grid order.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o osum_probe osum_probe.hip
 #include "../../recommender-system_amd/csrc/mf_sweep.hip.h"
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define CK(x)                                                                      \
@@ -46,12 +48,11 @@ int main(int argc, char **argv)
 	CK(hipMalloc(&drow, nrows * 4));
 	CK(hipMalloc(&dcnt, nrows * 4));
 	CK(hipMalloc(&dsbeg, nrows * 8));
-	{
-		std::vector<double> h(sbytes / 8);
-		for (size_t i = 0; i < h.size(); ++i) h[i] = (double) ((i * 2654435761u) & 1023) * 1e-3;
-		CK(hipMemcpy(scratch, h.data(), sbytes, hipMemcpyHostToDevice));
-	}
-	CK(hipMemset(Xo, 0, (size_t) nrows * ld * 8));
+	std::vector<double> hs(sbytes / 8), hx((size_t) nrows * ld);
+	for (size_t i = 0; i < hs.size(); ++i) hs[i] = (double) ((i * 2654435761u) & 1023) * 1.0000001e-3 - 0.3;
+	for (size_t i = 0; i < hx.size(); ++i) hx[i] = (double) ((i * 40503u) & 255) * 0.37;
+	CK(hipMemcpy(scratch, hs.data(), sbytes, hipMemcpyHostToDevice));
+	CK(hipMemcpy(Xo, hx.data(), hx.size() * 8, hipMemcpyHostToDevice));
 	CK(hipMemcpy(drow, row.data(), nrows * 4, hipMemcpyHostToDevice));
 	CK(hipMemcpy(dcnt, len.data(), nrows * 4, hipMemcpyHostToDevice));
 	CK(hipMemcpy(dsbeg, sbeg.data(), nrows * 8, hipMemcpyHostToDevice));
@@ -68,6 +69,10 @@ int main(int argc, char **argv)
 	o.scratch_entries = scratch_entries;
 	o.X_old = Xo;
 	o.X_new = Xn;
+	o.stamps = nullptr;
+	o.max_cnt = *std::max_element(len.begin(), len.end());
+	unsigned long long *dst;
+	CK(hipMalloc(&dst, (size_t) nrows * nsl * 32));
 	// a second buffer written between the timed launches, so the scratch is not served from L2 as a leftover
 	double *flush;
 	const size_t fbytes = 512u << 20;
@@ -96,5 +101,47 @@ int main(int argc, char **argv)
 		printf("%s side: %d rows, %lld entries, %d waves, lds %zu: avg %.1f us, best %.1f us = %.2f TB/s of scratch\n", shape, nrows,
 		       tot, nrows * nsl, lds, sum / reps * 1e3, best * 1e3, (double) tot * K * 8 / (best * 1e-3) / 1e12);
 	}
+	{   // against the serial sum on the host
+		std::vector<double> got((size_t) nrows * ld);
+		CK(hipMemcpy(got.data(), Xn, got.size() * 8, hipMemcpyDeviceToHost));
+		size_t bad = 0;
+		for (int i = 0; i < nrows; ++i)
+			for (int k = 0; k < K; ++k) {
+				double acc = hx[(size_t) i * ld + k];
+				const size_t sl = k / mf::kSliceCols, c = k % mf::kSliceCols;
+				for (int n = 0; n < len[i]; ++n) acc = acc + hs[((sl * scratch_entries + sbeg[i] + n) * mf::kSliceCols) + c];
+				bad += memcmp(&acc, &got[(size_t) i * ld + k], 8) != 0;
+			}
+		printf("against the serial sum on the host: %zu of %d values differ\n", bad, nrows * K);
+	}
+	// where the time of one launch goes: clock stamps of every (row, slice) task (100 MHz wall clock)
+	CK(hipFuncSetAttribute((const void *) mf::ordered_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, mf::kRing * 1024));
+	o.stamps = dst;
+	CK(hipMemsetAsync(flush, 7, fbytes, 0));
+	mf::ordered_sum_kernel<<<nrows * nsl, mf::kWave, mf::kRing * 1024, 0>>>(o);
+	CK(hipDeviceSynchronize());
+	std::vector<unsigned long long> st((size_t) nrows * nsl * 4);
+	CK(hipMemcpy(st.data(), dst, st.size() * 8, hipMemcpyDeviceToHost));
+	unsigned long long t0 = ~0ull, t1 = 0;
+	for (int i = 0; i < nrows * nsl; ++i) {
+		t0 = std::min(t0, st[4 * (size_t) i]);
+		t1 = std::max(t1, st[4 * (size_t) i + 2]);
+	}
+	printf("launch span %.1f us\n", (t1 - t0) * 0.01);
+	printf("task  row  len  start_us  prologue_us  stream_us  ns_per_block  hw_id\n");
+	for (int i = 0; i < nrows * nsl; i += (i < 40 ? 1 : 97)) {
+		const unsigned long long *q = &st[4 * (size_t) i];
+		const int li = i / nsl, nb = (len[li] + 15) / 16;
+		printf("%5d %4d %5d %8.1f %8.1f %8.1f %8.0f   %08llx\n", i, li, len[li], (q[0] - t0) * 0.01, (q[1] - q[0]) * 0.01,
+		       (q[2] - q[1]) * 0.01, (q[2] - q[1]) * 10.0 / nb, q[3]);
+	}
+	// waves resident over time (5-us bins)
+	const int nb = (int) ((t1 - t0) / 500) + 1;
+	std::vector<int> live(nb, 0);
+	for (int i = 0; i < nrows * nsl; ++i)
+		for (unsigned long long t = (st[4 * (size_t) i] - t0) / 500; t <= (st[4 * (size_t) i + 2] - t0) / 500; ++t) live[t]++;
+	printf("tasks alive per 5-us bin:");
+	for (int b = 0; b < nb; ++b) printf(" %d", live[b]);
+	printf("\n");
 	return 0;
 }
