@@ -488,7 +488,7 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 				if (v >= 1 && v <= 64 && (size_t) p->sweep.xs_bytes + (size_t) v * p->sweep.row_bytes <= kLdsPerCu) p->nch_prod = v;
 			}
 			p->lds_bytes_prod = (size_t) p->sweep.xs_bytes + (size_t) p->nch_prod * p->sweep.row_bytes;
-			p->lds_bytes_osum = (size_t) mf::kRing * 1024;
+			p->lds_bytes_osum = mf::kOrderedSumLds;
 			if (const char *env = getenv("MF_OS_LDS")) p->lds_bytes_osum = std::min<size_t>(kLdsPerCu, std::max<size_t>(p->lds_bytes_osum, (size_t) atoll(env)));
 			MF_TRY_HIP(raise_lds_limit((const void *) p->sweep.prod, p->lds_bytes_prod));
 			MF_TRY_HIP(raise_lds_limit((const void *) mf::ordered_sum_kernel, p->lds_bytes_osum));

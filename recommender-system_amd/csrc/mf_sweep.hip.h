@@ -421,7 +421,8 @@ struct OrderedSumArgs {
 	unsigned long long *stamps;           // probe builds only (tools/micro/osum_probe.hip): 4 clock stamps per task, else null
 };
 
-constexpr int kRing = 32;   // LDS ring slots of 1 KiB (a power of two; kRing-1 <= 63 = the largest vmcnt)
+constexpr int kRing = 32;   // LDS ring slots of 1 KiB (a power of two; kRing <= 63 = the largest vmcnt)
+constexpr size_t kOrderedSumLds = (size_t) (kRing + 1) * 1024;   // ring + the seed's slot
 
 typedef double v2d __attribute__((ext_vector_type(2)));
 
@@ -476,11 +477,24 @@ __device__ __forceinline__ void ordered_sum_task(const char *src, unsigned ring_
 		if (n > 14) MF_FMAC_BCAST(14);
 		if (n > 15) MF_FMAC_BCAST(15);
 	};
-	// Hand-counted region.  The seed is loaded from asm as well and BEFORE the blocks: loads return in order, so it has
-	// landed whenever block 0 has, and its round trip runs beside theirs instead of in front of them.
+	// Hand-counted region.  The seed travels like a block -- an LDS-DMA transfer into a slot of its own, issued BEFORE
+	// the blocks: LDS-DMA transfers land in order, so it has landed whenever block 0 has, and its round trip runs beside
+	// theirs instead of in front of them.  (An ordinary load into a register issued before the transfers is NOT ordered
+	// with them: on a busy chip the first add was seen to read the register before the load had returned.)
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing older in flight (the store of a previous task)
-	v2d seedv = {0.0, 0.0};
-	if (seed_ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(seedv) : "v"(seed_ptr) : "memory");
+	if (seed_ptr) {
+		const unsigned m0 = __builtin_amdgcn_readfirstlane(ring_base + (unsigned) kRing * 1024u);
+		asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(seed_ptr), "s"(m0) : "memory");
+	}
+	auto read_seed = [&]() {
+		v2d sv = {0.0, 0.0};
+		if (seed_ptr) {
+			const unsigned addr = my + (unsigned) kRing * 1024u;
+			asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(sv) : "v"(addr) : "memory");
+		}
+		ax = sv.x;
+		ay = sv.y;
+	};
 	const int ahead = min(nblk, D - 1);
 	for (int b = 0; b < ahead; ++b) issue(b);
 	t_issued = __builtin_amdgcn_s_memrealtime();   // (probe) no store inside the hand-counted region
@@ -490,9 +504,8 @@ __device__ __forceinline__ void ordered_sum_task(const char *src, unsigned ring_
 	// refilled after the adds of block b is free: its last reader was block b+D-1-kRing <= b-1, read two steps ago.
 	if (nblk > D - 1) {   // at least one block is still to be issued
 		v2d cur, nxt;
-		asm volatile("s_waitcnt vmcnt(%1)" : "+v"(seedv) : "n"(D - 2) : "memory");
-		ax = seedv.x;
-		ay = seedv.y;
+		asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 2) : "memory");
+		read_seed();
 		read_block(0, cur);
 		auto step = [&](int blk, v2d &have, v2d &want) {
 			landed(have);
@@ -516,9 +529,8 @@ __device__ __forceinline__ void ordered_sum_task(const char *src, unsigned ring_
 		++b;
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	} else {
-		asm volatile("s_waitcnt vmcnt(0)" : "+v"(seedv)::"memory");
-		ax = seedv.x;
-		ay = seedv.y;
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		read_seed();
 	}
 	for (; b < nblk; ++b) {
 		v2d v;
@@ -536,7 +548,7 @@ __device__ __forceinline__ void ordered_sum_task(const char *src, unsigned ring_
 __global__ void __launch_bounds__(kWave) ordered_sum_kernel(OrderedSumArgs a)
 {
 	static_assert(kSliceCols == 8, "row p of the wave = piece p of the slice: four pieces");
-	extern __shared__ __attribute__((aligned(1024))) char ring[];   // kRing * 1024 bytes
+	extern __shared__ __attribute__((aligned(1024))) char ring[];   // kOrderedSumLds bytes: the ring, then the seed's slot
 	const int lane = threadIdx.x, K = a.K;
 	const unsigned ring_base = (unsigned) (unsigned long long) (__attribute__((address_space(3))) char *) ring;
 	const int piece = lane >> 4, ent = lane & 15;
@@ -556,7 +568,8 @@ __global__ void __launch_bounds__(kWave) ordered_sum_kernel(OrderedSumArgs a)
 		const char *src = reinterpret_cast<const char *>(
 		                      a.scratch + (((size_t) slice * a.scratch_entries + (size_t) a.sbeg[li]) << kSliceShift)) +
 		                  64 * ent + 16 * piece;
-		const double *seed_ptr = (a.seed && live) ? a.X_old + (size_t) r * a.ldx + k0 : nullptr;
+		// every lane a valid address (the dead lanes of the last slice fetch column 0; they never store)
+		const double *seed_ptr = a.seed ? a.X_old + (size_t) r * a.ldx + (live ? k0 : 0) : nullptr;
 		double ax = 0.0, ay = 0.0;
 		// in flight: all of the ring for the longest rows, a half or a quarter of it for the shorter ones
 		if (4 * (long long) cnt >= 2 * (long long) a.max_cnt)

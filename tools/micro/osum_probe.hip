@@ -19,6 +19,27 @@
 		}                                                                          \
 	} while (0)
 
+// a stand-in for the sweep running beside the ordered sums: single-wave workgroups with a large LDS tile, read 16 bytes
+// per lane over and over (phase A / B of sweep_dma_kernel), plus some global traffic
+__global__ void __launch_bounds__(64) hammer(double *dst, const double *src, size_t n, int rounds)
+{
+	extern __shared__ __attribute__((aligned(16))) char tile[];
+	const int lane = threadIdx.x;
+	double2 acc = make_double2(0.0, 0.0);
+	for (int r = 0; r < rounds; ++r) {
+		const size_t base = ((size_t) blockIdx.x * 977 + (size_t) r * 131071) % (n - 8192);
+		for (int i = 0; i < 64; ++i) *reinterpret_cast<double2 *>(tile + i * 816 + 16 * (lane % 50)) = *reinterpret_cast<const double2 *>(src + base + i * 100 + 2 * (lane % 50));
+		__syncthreads();
+		for (int i = 0; i < 64; ++i) {
+			const double2 t = *reinterpret_cast<const double2 *>(tile + i * 816 + 16 * (lane % 50));
+			acc.x = acc.x + t.x;
+			acc.y = acc.y + t.y;
+		}
+		__syncthreads();
+	}
+	if (acc.x == 1.2345) dst[lane] = acc.y;
+}
+
 int main(int argc, char **argv)
 {
 	const int K = 100, ld = 100;
@@ -80,7 +101,7 @@ int main(int argc, char **argv)
 	hipEvent_t a, b;
 	CK(hipEventCreate(&a));
 	CK(hipEventCreate(&b));
-	const size_t lds_list[] = {(size_t) mf::kRing * 1024, 40000, 53000, 80000, 160000};
+	const size_t lds_list[] = {mf::kOrderedSumLds, 40000, 53000, 80000, 160000};
 	for (size_t lds : lds_list) {
 		CK(hipFuncSetAttribute((const void *) mf::ordered_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
 		float best = 1e9f, sum = 0.f;
@@ -114,11 +135,45 @@ int main(int argc, char **argv)
 			}
 		printf("against the serial sum on the host: %zu of %d values differ\n", bad, nrows * K);
 	}
+	if (argc > 2) {   // stress: many launches beside a memory-bound kernel on a second stream, every result checked
+		const int launches = atoi(argv[2]);
+		std::vector<double> want((size_t) nrows * ld, 0.0), got((size_t) nrows * ld);
+		for (int i = 0; i < nrows; ++i)
+			for (int k = 0; k < K; ++k) {
+				double acc = hx[(size_t) i * ld + k];
+				const size_t sl = k / mf::kSliceCols, c = k % mf::kSliceCols;
+				for (int n = 0; n < len[i]; ++n) acc = acc + hs[((sl * scratch_entries + sbeg[i] + n) * mf::kSliceCols) + c];
+				want[(size_t) i * ld + k] = acc;
+			}
+		hipStream_t s2;
+		CK(hipFuncSetAttribute((const void *) hammer, hipFuncAttributeMaxDynamicSharedMemorySize, 53248));
+		CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+		CK(hipFuncSetAttribute((const void *) mf::ordered_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) mf::kOrderedSumLds));
+		size_t bad_launches = 0, bad_values = 0;
+		for (int l = 0; l < launches; ++l) {
+			if (l % 2 == 0) hammer<<<4096, 64, 53248, s2>>>(flush, flush + (fbytes / 16), fbytes / 16, 40);
+			CK(hipMemsetAsync(Xn, 0, (size_t) nrows * ld * 8, 0));
+			mf::ordered_sum_kernel<<<nrows * nsl, mf::kWave, mf::kOrderedSumLds, 0>>>(o);
+			CK(hipMemcpy(got.data(), Xn, got.size() * 8, hipMemcpyDeviceToHost));
+			size_t bad = 0;
+			for (int i = 0; i < nrows; ++i)
+				for (int k = 0; k < K; ++k)
+					if (memcmp(&want[(size_t) i * ld + k], &got[(size_t) i * ld + k], 8) != 0) {
+						if (bad_values + bad < 12) printf("  launch %d row %d (len %d) col %d: want %.17g got %.17g\n", l, i, len[i], k, want[(size_t) i * ld + k], got[(size_t) i * ld + k]);
+						++bad;
+					}
+			bad_values += bad;
+			bad_launches += bad != 0;
+		}
+		CK(hipDeviceSynchronize());
+		printf("stress: %d launches, %zu with wrong values (%zu values)\n", launches, bad_launches, bad_values);
+		return 0;
+	}
 	// where the time of one launch goes: clock stamps of every (row, slice) task (100 MHz wall clock)
-	CK(hipFuncSetAttribute((const void *) mf::ordered_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, mf::kRing * 1024));
+	CK(hipFuncSetAttribute((const void *) mf::ordered_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, mf::kOrderedSumLds));
 	o.stamps = dst;
 	CK(hipMemsetAsync(flush, 7, fbytes, 0));
-	mf::ordered_sum_kernel<<<nrows * nsl, mf::kWave, mf::kRing * 1024, 0>>>(o);
+	mf::ordered_sum_kernel<<<nrows * nsl, mf::kWave, mf::kOrderedSumLds, 0>>>(o);
 	CK(hipDeviceSynchronize());
 	std::vector<unsigned long long> st((size_t) nrows * nsl * 4);
 	CK(hipMemcpy(st.data(), dst, st.size() * 8, hipMemcpyDeviceToHost));

@@ -1,0 +1,53 @@
+"""Which rows differ between a variant of the extreme-row path and the plain sweeps (debugging aid)."""
+import os, sys, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+import recommender_system_amd as rs
+capi = rs.capi
+cfg = bench.CONFIGS["cfg3"]
+U, I, K = cfg["users"], cfg["items"], cfg["feats"]
+counts, total = capi.synth_counts(cfg["seed"], U, I, cfg["min_row"], cfg["max_row"])
+row, col, val = bench.skewed_instance(cfg["seed"], U, I, total)
+L0, R0 = capi.init_factors(U, I, K)
+ulen = np.bincount(row, minlength=U); ilen = np.bincount(col, minlength=I)
+def run(env, iters=1):
+    saved = dict(os.environ)
+    os.environ.update(env)
+    try:
+        plan = capi.Plan(U, I, K, cfg["alpha"], row, col, val)
+        d = plan.describe()
+        plan.upload(L0, R0); plan.iterate(iters); out = plan.download(); plan.close()
+    finally:
+        os.environ.clear(); os.environ.update(saved)
+    return out, d
+variants = [dict(kv.split("=") for kv in a.split(",")) if a != "-" else {} for a in sys.argv[1:]] or [{}]
+def make(env):
+    saved = dict(os.environ)
+    os.environ.update(env)
+    try:
+        plan = capi.Plan(U, I, K, cfg["alpha"], row, col, val)
+    finally:
+        os.environ.clear(); os.environ.update(saved)
+    plan.upload(L0, R0)
+    return plan
+ref = make({"MF_SWEEP_SKEW": "0", "MF_ITER_MODE": "sweeps"})
+for env in variants:
+    env = dict(env, MF_ITER_MODE="sweeps")
+    var = make(env)
+    ref.upload(L0, R0)
+    bad = 0
+    for it in range(int(os.environ.get("DBG_ITERS", "400"))):
+        ref.iterate(1); var.iterate(1)
+        r = ref.download(); g = var.download()
+        bl = np.where((g[0] != r[0]).any(axis=1))[0]; br = np.where((g[1] != r[1]).any(axis=1))[0]
+        if len(bl) or len(br):
+            bad += 1
+            print(env, "iteration", it, "| L rows differ", len(bl), "lens", sorted(ulen[bl])[:6], "| R rows differ", len(br), "lens", sorted(ilen[br])[:6], flush=True)
+            for nm, b, gg, rr in (("L", bl, g[0], r[0]), ("R", br, g[1], r[1])):
+                for x in b[:3]:
+                    c = np.where(gg[x] != rr[x])[0]
+                    print("    ", nm, "row", x, "cols", c[:12], "n", len(c), "rel", float(np.max(np.abs(gg[x][c] - rr[x][c]) / np.abs(rr[x][c]))))
+            var.upload(r[0], r[1])
+            if bad >= 4: break
+    print(env, "done:", bad, "bad iterations", flush=True)
+    var.close()
