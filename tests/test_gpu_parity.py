@@ -174,6 +174,43 @@ def test_recommend_ties_masks_and_nan(capi, orc):
     assert best[5] == -1 and best[66] == -1
 
 
+@pytest.mark.parametrize("k", [6, 30, 100])
+def test_ordered_sums_every_depth_class_with_and_without_seed(capi, orc, monkeypatch, k):
+    """The extreme-row path on its own terms: item rows of 20 ... 2600 entries (all three in-flight depth classes of
+    ordered_sum_kernel, rows shorter than a ring, partial last blocks, a last slice that is only partly inside K) and
+    user rows of a few dozen entries beside them, through the sharded level-2 API so that the item sweep runs both
+    seeded from the old generation (root) and from zero (matFact-mpi.c:187) -- bit-exact against orc_shard_step."""
+    U, I = 2600, 48
+    rng = np.random.default_rng(1000 + k)
+    lens = np.unique(np.concatenate([[U, U - 1, 2049, 1040, 1025, 777, 512, 511, 300, 129, 128, 127, 65, 33, 20],
+                                     rng.integers(20, U, 12)]))[::-1]
+    rows, cols = [], []
+    for j, n in enumerate(lens[:I]):
+        r = np.sort(rng.choice(U, int(n), replace=False))
+        rows.append(r)
+        cols.append(np.full(len(r), j))
+    row = np.concatenate(rows).astype(np.int32)
+    col = np.concatenate(cols).astype(np.int32)
+    order = np.lexsort((col, row))                      # file order: by user, then item
+    row, col = row[order], col[order]
+    val = rng.integers(1, 6, len(row)).astype(np.float64)
+    alpha = 2e-4 / k
+    monkeypatch.setenv("MF_SWEEP_LONG", "24")           # (almost) every item row takes the products + ordered-sum path
+    L, R = capi.init_factors(U, I, k)
+    for root in (True, False):
+        plan = capi.Plan(U, I, k, alpha, row, col, val)
+        assert "long_rows=0/" not in plan.describe(), plan.describe()
+        plan.upload(L, R)
+        plan.sweep_items(seed_from_old=root)
+        plan.sweep_users()
+        plan.flip()
+        Ln, Ra = plan.download()
+        plan.close()
+        Lo, Rao = orc.shard_step(0, U, I, k, row, col, val, alpha, L, R, root)
+        assert np.array_equal(Ra, Rao), (k, root, np.where((Ra != Rao).any(axis=1))[0][:8])
+        assert np.array_equal(Ln, Lo), (k, root)
+
+
 def test_plan_sharded_sweeps_match_oracle_shard_step(capi, orc):
     """matFact-mpi.c:187-208 semantics of the level-2 API: per-shard aux buffers, root seeds from old."""
     d = random_instance(31, 90, 60, 20, density=0.3, iters=1, alpha=0.003)
