@@ -505,6 +505,36 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 			MF_TRY_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
 		}
 	}
+	// ---- a sweep of a few thousand rows is a handful of rounds of workgroups: in index order its tail is whatever
+	// long rows happen to start last.  Longest first (workgroups are dispatched in list order) the tail is made of the
+	// shortest rows.  cfg3 uniform (3952 / 6040 rows of 50..311 entries): see DESIGN 5.1.  Large sweeps keep the index
+	// order (the tail is a negligible part of them and neighbouring rows share lines of the entry arrays) except for rows
+	// several times longer than the average, which lead the list.
+	if (!getenv("MF_SWEEP_NOSORT"))
+		for (int kind = 0; kind < 2; ++kind) {
+			const std::vector<int> &pt = kind == 0 ? cptr : rptr;
+			const int nrows = kind == 0 ? p->items : p->uc;
+			if (p->n_long[kind] > 0 || p->coop_all[kind] || nrows < 512) continue;
+			auto len = [&](int r) { return pt[(size_t) r + 1] - pt[r]; };
+			auto longer = [&](int x, int y) { return len(x) > len(y); };
+			std::vector<int> order;
+			order.reserve((size_t) nrows);
+			if (nrows <= (1 << 17)) {
+				for (int r = 0; r < nrows; ++r) order.push_back(r);
+				std::stable_sort(order.begin(), order.end(), longer);
+			} else {
+				// a large sweep with a few very long rows (power-law users): only those move to the front
+				const long long mean = p->nnz / nrows;
+				if ((long long) p->max_row_len[kind] < 8 * std::max<long long>(mean, 1)) continue;
+				std::vector<int> head;
+				for (int r = 0; r < nrows; ++r) (len(r) >= 4 * mean ? head : order).push_back(r);
+				std::stable_sort(head.begin(), head.end(), longer);
+				order.insert(order.begin(), head.begin(), head.end());
+			}
+			MF_TRY(dev_alloc(&p->short_rows[kind], order.size()));
+			MF_TRY_HIP(hipMemcpy(p->short_rows[kind], order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
+			p->lpt[kind] = true;
+		}
 	return MF_OK;
 }
 

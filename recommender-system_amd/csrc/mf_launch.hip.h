@@ -145,7 +145,7 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 		a.Y_old = p->Rbuf[p->cur];
 		a.X_new = p->Lbuf[nxt];
 	}
-	a.rowlist = nullptr;
+	a.rowlist = p->lpt[kind] ? p->short_rows[kind] : nullptr;
 	a.seg_row = a.seg_beg = a.seg_end = nullptr;
 	a.seg_out = nullptr;
 	a.scratch = nullptr;

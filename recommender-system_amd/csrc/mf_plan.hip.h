@@ -152,6 +152,7 @@ struct mf_plan {
 	// skew-aware split of a sweep with many rows: rows whose serial walk would dominate the launch go to the
 	// row-cooperative kernel on a side stream, the others stay on the single-wave kernel
 	int *long_rows[2] = {nullptr, nullptr}, *short_rows[2] = {nullptr, nullptr};
+	bool lpt[2] = {false, false};   // short_rows[kind] = ALL rows, longest first: the order of a sweep without extreme rows
 	int n_long[2] = {0, 0}, n_short[2] = {0, 0};
 	// extreme rows of LARGE sweeps: 256-entry segments -> scaled rows in `scratch` -> ordered sum
 	int n_seg[2] = {0, 0};
