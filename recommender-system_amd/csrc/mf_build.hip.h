@@ -519,7 +519,7 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 			auto longer = [&](int x, int y) { return len(x) > len(y); };
 			std::vector<int> order;
 			order.reserve((size_t) nrows);
-			if (nrows <= (1 << 17)) {
+			if (nrows <= (1 << 15)) {   // a dozen rounds of workgroups at most: the tail matters, the order of the row reads does not
 				for (int r = 0; r < nrows; ++r) order.push_back(r);
 				std::stable_sort(order.begin(), order.end(), longer);
 			} else {
