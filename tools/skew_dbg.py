@@ -4,10 +4,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 import recommender_system_amd as rs
 capi = rs.capi
-cfg = bench.CONFIGS["cfg3"]
-U, I, K = cfg["users"], cfg["items"], cfg["feats"]
-counts, total = capi.synth_counts(cfg["seed"], U, I, cfg["min_row"], cfg["max_row"])
-row, col, val = bench.skewed_instance(cfg["seed"], U, I, total)
+if os.environ.get("DBG_CFG") == "nflx10":   # a tenth of the Netflix shape, K=30 (partly filled last slice)
+    cfg = dict(bench.CONFIGS["nflx"], alpha=1e-6)
+    U, I, K = cfg["users"] // 10, cfg["items"] // 4, 30
+    row, col, val = bench.power_law_large(cfg["seed"], U, I, cfg["power_law_nnz"] // 10)
+else:
+    cfg = bench.CONFIGS["cfg3"]
+    U, I, K = cfg["users"], cfg["items"], cfg["feats"]
+    counts, total = capi.synth_counts(cfg["seed"], U, I, cfg["min_row"], cfg["max_row"])
+    row, col, val = bench.skewed_instance(cfg["seed"], U, I, total)
 L0, R0 = capi.init_factors(U, I, K)
 ulen = np.bincount(row, minlength=U); ilen = np.bincount(col, minlength=I)
 def run(env, iters=1):
