@@ -211,6 +211,30 @@ def test_ordered_sums_every_depth_class_with_and_without_seed(capi, orc, monkeyp
         assert np.array_equal(Ln, Lo), (k, root)
 
 
+def test_dispatch_order_of_a_large_skewed_sweep(capi, orc):
+    """More than 32768 users, a few of them ten times longer than the average but below the extreme-row threshold:
+    the user sweep runs from a row list with those rows first and the rest in index order; the item sweep (300 rows)
+    keeps the plain order.  One iteration, bit-exact against the oracle."""
+    U, I, K = 40000, 300, 100
+    rng = np.random.default_rng(77)
+    lens = rng.integers(20, 41, U)
+    lens[rng.choice(U, 60, replace=False)] = rng.integers(250, 301, 60)
+    row = np.repeat(np.arange(U, dtype=np.int32), lens)
+    col = np.concatenate([np.sort(rng.choice(I, int(n), replace=False)) for n in lens]).astype(np.int32)
+    val = rng.integers(1, 6, len(row)).astype(np.float64)
+    d = dict(iters=1, alpha=1e-5, feats=K, users=U, items=I, row=row, col=col, val=val)
+    plan = capi.Plan(U, I, K, d["alpha"], row, col, val)
+    desc = plan.describe()
+    L, R = capi.init_factors(U, I, K)
+    plan.upload(L, R)
+    plan.iterate(1)
+    Lg, Rg = plan.download()
+    plan.close()
+    Lo, Ro = orc.init_factors(U, I, K)
+    orc.factorize(orc.Instance(**d), Lo, Ro, iters=1)
+    assert "long_rows=" in desc and np.array_equal(Lg, Lo) and np.array_equal(Rg, Ro), desc
+
+
 def test_plan_sharded_sweeps_match_oracle_shard_step(capi, orc):
     """matFact-mpi.c:187-208 semantics of the level-2 API: per-shard aux buffers, root seeds from old."""
     d = random_instance(31, 90, 60, 20, density=0.3, iters=1, alpha=0.003)
