@@ -6,7 +6,7 @@ import recommender_system_amd as rs
 capi = rs.capi
 if os.environ.get("DBG_CFG") == "nflx10":   # a tenth of the Netflix shape, K=30 (partly filled last slice)
     cfg = dict(bench.CONFIGS["nflx"], alpha=1e-6)
-    U, I, K = cfg["users"] // 10, cfg["items"] // 4, 30
+    U, I, K = cfg["users"] // 10, cfg["items"] // 4, int(os.environ.get("DBG_K", "30"))
     row, col, val = bench.power_law_large(cfg["seed"], U, I, cfg["power_law_nnz"] // 10)
 else:
     cfg = bench.CONFIGS["cfg3"]
@@ -39,6 +39,7 @@ ref = make({"MF_SWEEP_SKEW": "0", "MF_ITER_MODE": "sweeps"})
 for env in variants:
     env = dict(env, MF_ITER_MODE="sweeps")
     var = make(env)
+    print(env, var.describe().split("row_bytes")[1][:120], flush=True)
     ref.upload(L0, R0)
     bad = 0
     for it in range(int(os.environ.get("DBG_ITERS", "400"))):
