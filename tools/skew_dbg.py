@@ -25,6 +25,11 @@ def run(env, iters=1):
     finally:
         os.environ.clear(); os.environ.update(saved)
     return out, d
+noise = noise_stream = None
+if os.environ.get("DBG_NOISE"):
+    import torch
+    noise_stream = torch.cuda.Stream()
+    noise = torch.ones(64 << 20, dtype=torch.float64, device="cuda")   # 512 MB: ~0.3 ms per pass
 variants = [dict(kv.split("=") for kv in a.split(",")) if a != "-" else {} for a in sys.argv[1:]] or [{}]
 def make(env):
     saved = dict(os.environ)
@@ -43,6 +48,9 @@ for env in variants:
     ref.upload(L0, R0)
     bad = 0
     for it in range(int(os.environ.get("DBG_ITERS", "400"))):
+        if noise is not None:   # a memory-bound neighbour on another stream while the variant iterates
+            with torch.cuda.stream(noise_stream):
+                for _ in range(4): noise.mul_(1.0000001)
         ref.iterate(1); var.iterate(1)
         r = ref.download(); g = var.download()
         bl = np.where((g[0] != r[0]).any(axis=1))[0]; br = np.where((g[1] != r[1]).any(axis=1))[0]
