@@ -499,7 +499,7 @@ __device__ __forceinline__ void ordered_sum_task(const char *src, unsigned ring_
 	for (int b = 0; b < ahead; ++b) issue(b);
 	t_issued = __builtin_amdgcn_s_memrealtime();   // (probe) no store inside the hand-counted region
 	int b = 0;
-	// Steady state: the read of block b+1 is in flight under the 16 dependent adds of block b (the true critical path).
+	// Steady state: the 16 dependent adds of block b (the true critical path), then the read of block b+1.
 	// D-1 blocks are issued beyond b-1, so block b+1 has landed once at most D-3 newer DMAs are outstanding; the slot
 	// refilled after the adds of block b is free: its last reader was block b+D-1-kRing <= b-1, read two steps ago.
 	if (nblk > D - 1) {   // at least one block is still to be issued
@@ -507,11 +507,17 @@ __device__ __forceinline__ void ordered_sum_task(const char *src, unsigned ring_
 		asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 2) : "memory");
 		read_seed();
 		read_block(0, cur);
+		// The LDS read of the next block is issued AFTER the adds, never before them: an LDS read returning into
+		// registers while the v_fmac_f64_dpp chain executes was seen to corrupt the chain -- one entry of one block
+		// (all four DPP rows, both columns) every ~1e8 blocks, only beside the sweep of the remaining rows on a busy
+		// chip (tools/skew_dbg.py on the tenth-scale Netflix shape with MF_SWEEP_LONG=3000: 4 bad iterations per ~150;
+		// with the read after the adds, or without DPP, none in 1200).  The read's latency is then exposed at the top
+		// of the next step; the DMA issue in between hides a part of it, the iteration loses 0.5 %.
 		auto step = [&](int blk, v2d &have, v2d &want) {
 			landed(have);
+			add16(have);
 			asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 3) : "memory");
 			read_block(blk + 1, want);
-			add16(have);
 			issue(blk + D - 1);
 		};
 		for (; b + D < nblk; b += 2) {   // two blocks per trip: the two registers swap roles, no copies
