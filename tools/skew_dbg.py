@@ -8,6 +8,12 @@ if os.environ.get("DBG_CFG") == "nflx10":   # a tenth of the Netflix shape, K=30
     cfg = dict(bench.CONFIGS["nflx"], alpha=1e-6)
     U, I, K = cfg["users"] // 10, cfg["items"] // 4, int(os.environ.get("DBG_K", "30"))
     row, col, val = bench.power_law_large(cfg["seed"], U, I, cfg["power_law_nnz"] // 10)
+elif os.environ.get("DBG_CFG") == "ml100k":   # the errors + resident-streams iteration against the plain sweeps
+    cfg = bench.CONFIGS["ml100k"]
+    inst = capi.parse_file(cfg["file"])
+    U, I, K = inst.users, inst.items, inst.feats
+    row, col, val = inst.row, inst.col, inst.val
+    cfg = dict(cfg, alpha=float(os.environ.get("DBG_ALPHA", "1e-4")))
 else:
     cfg = bench.CONFIGS["cfg3"]
     U, I, K = cfg["users"], cfg["items"], cfg["feats"]
@@ -42,7 +48,7 @@ def make(env):
     return plan
 ref = make({"MF_SWEEP_SKEW": "0", "MF_ITER_MODE": "sweeps"})
 for env in variants:
-    env = dict(env, MF_ITER_MODE="sweeps")
+    env = dict(env, MF_ITER_MODE=os.environ.get("DBG_MODE", "sweeps"))
     var = make(env)
     print(env, var.describe().split("row_bytes")[1][:120], flush=True)
     ref.upload(L0, R0)
