@@ -29,11 +29,13 @@
 extern "C" {
 #endif
 
-#define MATFACT_HIP_ABI_VERSION 4   /* 2: mf_shard.users_ext, seeded user sweep, scored recommend (2-D tiles)
+#define MATFACT_HIP_ABI_VERSION 5   /* 2: mf_shard.users_ext, seeded user sweep, scored recommend (2-D tiles)
                                        3: mf_backend_multi_last_timing, MF_MULTI_REDUCE=peer|rccl; the reserved
                                           MF_PLAN_RELAXED_ORDER flag is gone (never implemented: an atomic sum is
                                           order-nondeterministic and slower than the owner-computes gather)
-                                       4: mf_shard.items_pitch / users_pitch, mf_backend_row_pitch, mf_plan_row_pitch */
+                                       4: mf_shard.items_pitch / users_pitch, mf_backend_row_pitch, mf_plan_row_pitch
+                                       5: mf_backend_multi_last_counters (one host thread per shard enqueues its
+                                          iterations; MF_MULTI_THREADS=0 keeps the single enqueueing thread) */
 
 /* == non_zero_entry, datatypes.h:10-15: the (user, item, rating) triple, 16 bytes, array-of-structs */
 typedef struct mf_entry {
@@ -100,6 +102,12 @@ int mf_backend_run_multi(const mf_problem *p, double *L, double *R, int32_t *bes
  * iterations, recommendations; info[0] = shards, info[1] = reducer (0 peer, 1 rccl), info[2] = 1 when the shards
  * were slices of the caller's array (input sorted by the cut key: no bucketing pass).  Any pointer may be NULL. */
 int mf_backend_multi_last_timing(double *setup_s, double *iterate_s, double *recommend_s, int *info);
+/* More of the same run: enqueue_s = host time the slowest enqueueing thread spent issuing the iterations' launches, event
+ * records and waits (everything of iterate_s but the final synchronize; small against iterate_s = the host is not the
+ * bound); entry_passes = passes of the host over all nnz entries during set-up (1: the counting pass; 2: + the stable
+ * scatter of an input not sorted by the cut key) -- independent of the shard count; host_threads = threads that
+ * enqueued (the shard count, or 1 with MF_MULTI_THREADS=0).  Any pointer may be NULL. */
+int mf_backend_multi_last_counters(double *enqueue_s, int64_t *entry_passes, int *host_threads);
 
 /* ------------------------------------------------------------------------------------------ LEVEL 2 */
 

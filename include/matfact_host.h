@@ -47,8 +47,9 @@ int mf_host_parse_buffer(const char *text, size_t len, mf_problem *p);
 void mf_host_free_problem(mf_problem *p);
 /* The same through a binary cache (the reference re-parses with fscanf on every run, util.c:30-34):
  * cache_dir/<content hash>-<size>.mfcache holds the header and the entries as parsed, keyed by the CONTENT of the
- * `.in` (an edited file never hits a stale cache).  Miss: parse, then write the cache (best effort, write-then-rename).
- * Hit: the cache file is mapped and p->entries points into the mapping -- no parse, no copy; *cache_hit = 1.
+ * `.in` (a 64-bit hash + the size: an edited file misses).  Miss: parse, then write the cache (best effort,
+ * write-then-rename).  Hit: the cache file is mapped, the hash of its entries checked against its header, and p->entries
+ * points into the mapping -- no parse, no copy; *cache_hit = 1.  Thread-safe; any number of cached problems may be open.
  * cache_dir NULL or "": plain mf_host_parse_file.  Release with mf_host_free_problem either way. */
 int mf_host_parse_file_cached(const char *path, const char *cache_dir, mf_problem *p, int *cache_hit);
 

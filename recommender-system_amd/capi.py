@@ -27,7 +27,7 @@ MF_ERR_ARGUMENT, MF_ERR_NO_DEVICE, MF_ERR_HIP, MF_ERR_NO_MEMORY, MF_ERR_UNSUPPOR
 HIP_SYMBOLS = [
     "mf_backend_strerror", "mf_backend_last_hip_error", "mf_backend_abi_version", "mf_backend_device_count",
     "mf_backend_factorize", "mf_backend_recommend", "mf_backend_run", "mf_backend_run_multi", "mf_backend_run_top1",
-    "mf_backend_multi_last_timing",
+    "mf_backend_multi_last_timing", "mf_backend_multi_last_counters",
     "mf_plan_create", "mf_backend_row_pitch", "mf_plan_row_pitch", "mf_plan_destroy", "mf_plan_set_stream", "mf_plan_upload_factors",
     "mf_plan_download_factors", "mf_plan_iterate", "mf_plan_sweep_items", "mf_plan_sweep_users",
     "mf_plan_items_next", "mf_plan_items_current", "mf_plan_flip", "mf_plan_recommend", "mf_plan_recommend_info",
@@ -107,6 +107,7 @@ def hip():
         lib.mf_backend_run_multi.argtypes = [C.POINTER(Problem), _f64p, _f64p, _i32p, _i32p, C.c_int]
         lib.mf_backend_multi_last_timing.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double),
                                                      C.POINTER(C.c_double), C.POINTER(C.c_int * 3)]
+        lib.mf_backend_multi_last_counters.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int)]
         lib.mf_backend_run_top1.argtypes = [C.POINTER(Problem), _f64p, _f64p, _i32p, C.c_int]
         lib.mf_backend_factorize.argtypes = [C.POINTER(Problem), _f64p, _f64p, C.c_int]
         lib.mf_backend_recommend.argtypes = [C.POINTER(Problem), _f64p, _f64p, _i32p, C.c_int]
@@ -372,13 +373,18 @@ def backend_run_multi(inst, L, R, devices, iters=None):
 
 
 def multi_last_timing():
-    """Host wall-clock of the last backend_run_multi: dict(setup_s, iterate_s, recommend_s, shards, reducer, sliced)."""
-    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    """Host wall-clock and counters of the last backend_run_multi: dict(setup_s, iterate_s, recommend_s, shards, reducer,
+    sliced, enqueue_s, entry_passes, host_threads)."""
+    a, b, c, e = C.c_double(), C.c_double(), C.c_double(), C.c_double()
     info = (C.c_int * 3)()
+    passes, threads = C.c_int64(), C.c_int()
     _check(hip().mf_backend_multi_last_timing(C.byref(a), C.byref(b), C.byref(c), C.byref(info)),
            "mf_backend_multi_last_timing")
+    _check(hip().mf_backend_multi_last_counters(C.byref(e), C.byref(passes), C.byref(threads)),
+           "mf_backend_multi_last_counters")
     return {"setup_s": a.value, "iterate_s": b.value, "recommend_s": c.value, "shards": info[0],
-            "reducer": "rccl" if info[1] else "peer", "sliced": bool(info[2])}
+            "reducer": "rccl" if info[1] else "peer", "sliced": bool(info[2]), "enqueue_s": e.value,
+            "entry_passes": passes.value, "host_threads": threads.value}
 
 
 def backend_run_top1(inst, L0, R0, iters=None, device=0):

@@ -283,8 +283,7 @@ int build_on_device(mf_plan *p, const mf_shard *s, const mf_entry *aos, bool swa
 int build_sparse(mf_plan *p, const mf_shard *s_in, const mf_entry *aos, bool swap, std::vector<int> &rptr,
                  std::vector<int> &cptr)
 {
-	const char *where = getenv("MF_BUILD");
-	if (where && strcmp(where, "host") == 0) {
+	if (p->cfg.build_host) {   // MF_BUILD=host
 		// host fallback of the BUILD only (tests): works on the three arrays
 		mf_shard sh = *s_in;
 		std::vector<int32_t> hrow, hcol;
@@ -373,17 +372,14 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 	// ---- long / short row lists.  A row is "long" when its serial walk (~0.075 us per entry at 16-entry
 	// chunks) would exceed roughly a quarter of the bandwidth time of the whole sweep (nnz * 8K bytes at
 	// ~7 TB/s): len > 4e-6 * nnz * K, and never below 128 entries.  cfg4 has none; a power-law instance a few.
-	const char *skew_env = getenv("MF_SWEEP_SKEW");   // "0" disables the split
-	if (p->sweep.prod && !(skew_env && skew_env[0] == '0')) {
+	const mf_config &cfg = p->cfg;
+	if (p->sweep.prod && cfg.skew) {   // MF_SWEEP_SKEW=0 disables the split
 		const size_t per_entry = 2 * (size_t) mf::kCoopProducers * (size_t) p->sweep.row_bytes;
 		const size_t head = (size_t) p->sweep.xs_bytes;
 		int nl = (int) std::min<size_t>(32, (kLdsPerCu - 4096 - head) / per_entry);
-		if (const char *env = getenv("MF_SWEEP_NCH")) {
-			const int v = atoi(env);
-			if (v >= 1 && v <= 64 && head + (size_t) v * per_entry <= kLdsPerCu) nl = v;
-		}
+		if (const int v = cfg.sweep_nch; v >= 1 && head + (size_t) v * per_entry <= kLdsPerCu) nl = v;
 		double thr = 4e-6 * (double) p->nnz * (double) p->K;
-		if (const char *t = getenv("MF_SWEEP_LONG")) thr = atof(t);
+		if (cfg.sweep_long_set) thr = cfg.sweep_long;
 		const int t_long = std::max(128, (int) std::min(thr, 2e9));
 		// estimated bandwidth time of one sweep; below ~50 us the two-stream fork/join (tens of us on the 6000
 		// launches of ML100k) costs more than the split saves: use one cooperative launch for all rows there
@@ -395,12 +391,12 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 			const int nrows = kind == 0 ? p->items : p->uc;
 			// ... and only rows well above the average count as long: when every row is equally long (the cfg4
 			// twin: 1000 items x 1000 entries) there is no skew to fix and the single-wave kernel is the faster one
-			const int t_kind = getenv("MF_SWEEP_LONG") ? t_long : std::max(t_long, (int) std::min<long long>(4 * (long long) (p->nnz / std::max(nrows, 1)), 2000000000ll));
+			const int t_kind = cfg.sweep_long_set ? t_long : std::max(t_long, (int) std::min<long long>(4 * (long long) (p->nnz / std::max(nrows, 1)), 2000000000ll));
 			if (p->max_row_len[kind] < t_kind) continue;
-			if (est_us < 50.0 && nrows < 4096 && !getenv("MF_SWEEP_LONG")) {
-				if (p->sweep.coop && (nc >= 8 || getenv("MF_SWEEP_NCH"))) {
+			if (est_us < 50.0 && nrows < 4096 && !cfg.sweep_long_set) {
+				if (p->sweep.coop && (nc >= 8 || cfg.sweep_nch)) {
 					p->coop_all[kind] = true;
-					p->nch_coop = getenv("MF_SWEEP_NCH") ? nl : nc;
+					p->nch_coop = cfg.sweep_nch ? nl : nc;
 					p->lds_bytes_coop = head + (size_t) p->nch_coop * per_entry;
 				}
 				continue;
@@ -422,14 +418,27 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 				t_eff *= 2;
 			}
 			if (p->max_row_len[kind] < t_eff) continue;
-			std::vector<int> lg, sh;
-			for (int r = 0; r < nrows; ++r) (pt[(size_t) r + 1] - pt[r] >= t_eff ? lg : sh).push_back(r);
+			std::vector<int> lg, sh, md;
+			// mid-length rows: at least t_mid entries (default: a quarter of the extreme threshold, never below 4x the mean)
+			const int t_mid = !p->sweep.db || cfg.sweep_mid == 0 ? t_eff
+			                  : cfg.sweep_mid > 0            ? std::min(cfg.sweep_mid, t_eff)
+			                                                 : std::min(t_eff, std::max(t_eff / 4, (int) std::min<long long>(4 * (long long) (p->nnz / std::max(nrows, 1)), 1 << 30)));
+			for (int r = 0; r < nrows; ++r) {
+				const int len = pt[(size_t) r + 1] - pt[r];
+				(len >= t_eff ? lg : len >= t_mid ? md : sh).push_back(r);
+			}
 			// longest first: workgroups are dispatched in list order as slots free up, so the long walks start
 			// at once and the short rows fill in behind them (longest-processing-time-first scheduling)
 			auto by_len = [&](int x, int y) { return pt[(size_t) x + 1] - pt[x] > pt[(size_t) y + 1] - pt[y]; };
-			if (!getenv("MF_SWEEP_NOSORT")) {
+			if (!cfg.nosort) {
 				std::stable_sort(sh.begin(), sh.end(), by_len);
+				std::stable_sort(md.begin(), md.end(), by_len);
 				std::stable_sort(lg.begin(), lg.end(), by_len);
+			}
+			if (!md.empty()) {
+				MF_TRY(dev_alloc(&p->mid_rows[kind], md.size()));
+				MF_TRY_HIP(hipMemcpy(p->mid_rows[kind], md.data(), md.size() * sizeof(int), hipMemcpyHostToDevice));
+				p->n_mid[kind] = (int) md.size();
 			}
 			MF_TRY(dev_alloc(&p->long_rows[kind], lg.size()));
 			MF_TRY(dev_alloc(&p->short_rows[kind], sh.size()));
@@ -437,12 +446,13 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 			if (!sh.empty())
 				MF_TRY_HIP(hipMemcpy(p->short_rows[kind], sh.data(), sh.size() * sizeof(int), hipMemcpyHostToDevice));
 			p->n_long[kind] = (int) lg.size();
+			p->long_len[kind] = t_eff;
 			p->n_short[kind] = (int) sh.size();
 			// segments of 256 entries; scratch offsets in entry units, rows back to back
 			// entries per segment of the products launch: one wave walks a segment chunk by chunk (~2.5 us per 16 entries
 			// of exposed latency), so short segments finish sooner and there are more of them to overlap
 			// (cfg3 power-law: 256 -> 64 entries 0.452 -> 0.421 ms per iteration; Netflix-shaped 21.6 -> 21.4 ms)
-			const int kSeg = getenv("MF_SWEEP_SEG") ? std::max(16, atoi(getenv("MF_SWEEP_SEG"))) : 64;
+			const int kSeg = cfg.sweep_seg;
 			std::vector<int> srow, sbeg, send, lcnt;
 			std::vector<long long> sout, lbeg;
 			long long off = 0;
@@ -476,22 +486,19 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 		if (p->coop_all[0] || p->coop_all[1])
 			MF_TRY_HIP(raise_lds_limit((const void *) p->sweep.coop, p->lds_bytes_coop));
 		if (p->n_long[0] || p->n_long[1]) {
-			if (const char *env = getenv("MF_SWEEP_REST"); env && strcmp(env, "coop") == 0 && p->sweep.coop) {
+			if (cfg.rest_coop && p->sweep.coop) {
 				p->rest_coop = true;
-				p->nch_coop = getenv("MF_SWEEP_NCH") ? nl : nc;
+				p->nch_coop = cfg.sweep_nch ? nl : nc;
 				p->lds_bytes_coop = head + (size_t) p->nch_coop * per_entry;
 				MF_TRY_HIP(raise_lds_limit((const void *) p->sweep.coop, p->lds_bytes_coop));
 			}
 			p->nch_prod = p->nch;
-			if (const char *env = getenv("MF_SWEEP_PNCH")) {
-				const int v = atoi(env);
-				if (v >= 1 && v <= 64 && (size_t) p->sweep.xs_bytes + (size_t) v * p->sweep.row_bytes <= kLdsPerCu) p->nch_prod = v;
-			}
+			if (const int v = cfg.sweep_pnch; v >= 1 && v <= 64 && (size_t) p->sweep.xs_bytes + (size_t) v * p->sweep.row_bytes <= kLdsPerCu) p->nch_prod = v;
 			p->lds_bytes_prod = (size_t) p->sweep.xs_bytes + (size_t) p->nch_prod * p->sweep.row_bytes;
 			p->lds_bytes_osum = mf::kOrderedSumLds;
-			if (const char *env = getenv("MF_OS_LDS")) p->lds_bytes_osum = std::min<size_t>(kLdsPerCu, std::max<size_t>(p->lds_bytes_osum, (size_t) atoll(env)));
+			if (cfg.os_lds) p->lds_bytes_osum = std::min<size_t>(kLdsPerCu, std::max<size_t>(p->lds_bytes_osum, cfg.os_lds));
 			MF_TRY_HIP(raise_lds_limit((const void *) p->sweep.prod, p->lds_bytes_prod));
-			MF_TRY_HIP(raise_lds_limit((const void *) mf::ordered_sum_kernel, p->lds_bytes_osum));
+			MF_TRY_HIP(raise_lds_limit(cfg.os_dpp ? (const void *) mf::ordered_sum_kernel<true> : (const void *) mf::ordered_sum_kernel<false>, p->lds_bytes_osum));
 			// [slice][entry][kSliceCols doubles]; one block of padding per slice: the last block of a row is read whole
 			p->scratch_entries = (size_t) scratch_entries + mf::kBlockEntries;
 			MF_TRY(dev_alloc(&p->scratch, p->scratch_entries * mf::kSliceCols *
@@ -503,14 +510,66 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 			MF_TRY_HIP(hipStreamCreateWithPriority(&p->side_stream, hipStreamNonBlocking, prio_hi));
 			MF_TRY_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
 			MF_TRY_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+			if (p->n_mid[0] || p->n_mid[1]) {
+				// two tiles of nch_mid rows: as many as fit a third of a CU's LDS (K=100: 32 rows, 53 KB, three per CU)
+				const size_t rb = (size_t) p->sweep.row_bytes, hd = (size_t) p->sweep.xs_bytes;
+				int nm = cfg.mid_nch > 0 ? cfg.mid_nch : 32;
+				while (nm > 4 && hd + 2 * (size_t) nm * rb > kLdsPerCu / (cfg.mid_nch > 0 ? 1 : 3)) --nm;
+				p->nch_mid = std::min(nm, 64);
+				p->lds_bytes_mid = hd + 2 * (size_t) p->nch_mid * rb;
+				p->mid_coop = cfg.mid_coop && p->sweep.coop;
+				if (p->mid_coop) {   // 2 buffers x 7 producers x nch rows
+					int nc2 = cfg.mid_nch > 0 ? cfg.mid_nch : 13;
+					while (nc2 > 1 && hd + (size_t) nc2 * per_entry > kLdsPerCu - 2048) --nc2;
+					p->nch_mid = nc2;
+					p->lds_bytes_mid = hd + (size_t) nc2 * per_entry;
+					MF_TRY_HIP(raise_lds_limit((const void *) p->sweep.coop, p->lds_bytes_mid));
+				} else
+				MF_TRY_HIP(raise_lds_limit((const void *) p->sweep.db, p->lds_bytes_mid));
+				MF_TRY_HIP(hipStreamCreateWithPriority(&p->mid_stream, hipStreamNonBlocking, prio_hi));
+				MF_TRY_HIP(hipEventCreateWithFlags(&p->ev_mid_join, hipEventDisableTiming));
+			}
 		}
+	}
+	// ---- wave priority for the long rows of the single-wave launch (what the launch ends on): when the launch is skewed
+	// (its longest row at least four times its mean), rows of at least twice the mean run at raised priority
+	for (int kind = 0; kind < 2; ++kind) {
+		const std::vector<int> &pt = kind == 0 ? cptr : rptr;
+		const int nrows = kind == 0 ? p->items : p->uc;
+		long long ent = 0, rows = 0;
+		int longest = 0;
+		for (int r = 0; r < nrows; ++r) {
+			const int len = pt[(size_t) r + 1] - pt[r];
+			if (p->n_long[kind] > 0 && len >= p->long_len[kind]) continue;   // on the extreme-row path
+			ent += len;
+			++rows;
+			longest = std::max(longest, len);
+		}
+		const long long mean = rows ? ent / rows : 0;
+		p->prio_len[kind] = 0;
+		if (p->cfg.sweep_prio > 0)
+			p->prio_len[kind] = p->cfg.sweep_prio;
+		else if (p->cfg.sweep_prio < 0 && rows > 256 && longest >= 4 * std::max<long long>(mean, 1))
+			p->prio_len[kind] = (int) std::max<long long>(64, 2 * mean);
+	}
+	// ---- double-buffered single-wave form for the WHOLE single-wave launch: measured slower than the single-buffered form
+	// whenever the launch has more rows than double-tile workgroups fit the chip (cfg3 uniform 0.222 -> 0.429 ms: the
+	// second tile halves the resident workgroups and the CU's gather rate is shared by fewer requests in flight), so it
+	// is off unless forced (MF_SWEEP_DB=1) or the launch is below MF_SWEEP_DB_ROWS rows (experiments build).  Its use is
+	// the mid-length rows' launch above.
+	for (int kind = 0; kind < 2; ++kind) {
+		const int nrows = kind == 0 ? p->items : p->uc;
+		const int launch_rows = p->n_long[kind] > 0 ? p->n_short[kind] : nrows;
+		const int limit = p->cfg.db_rows;
+		p->use_db[kind] = p->sweep.db && !p->coop_all[kind] && !p->rest_coop && launch_rows > 0 &&
+		                  (p->cfg.sweep_db == 1 || (p->cfg.sweep_db < 0 && launch_rows <= limit));
 	}
 	// ---- a sweep of a few thousand rows is a handful of rounds of workgroups: in index order its tail is whatever
 	// long rows happen to start last.  Longest first (workgroups are dispatched in list order) the tail is made of the
 	// shortest rows.  cfg3 uniform (3952 / 6040 rows of 50..311 entries): see DESIGN 5.1.  Large sweeps keep the index
 	// order (the tail is a negligible part of them and neighbouring rows share lines of the entry arrays) except for rows
 	// several times longer than the average, which lead the list.
-	if (!getenv("MF_SWEEP_NOSORT"))
+	if (!p->cfg.nosort)
 		for (int kind = 0; kind < 2; ++kind) {
 			const std::vector<int> &pt = kind == 0 ? cptr : rptr;
 			const int nrows = kind == 0 ? p->items : p->uc;
@@ -546,10 +605,7 @@ int plan_es_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vector
 	if (!p->want_map || !p->csr2csc) return MF_OK;
 	const size_t row_bytes = (size_t) p->sweep.row_bytes, head = (size_t) p->sweep.xs_bytes;
 	int nch = (int) std::min<size_t>(64, (kLdsPerCu / 3 - head) / row_bytes);
-	if (const char *env = getenv("MF_ES_NCH")) {
-		const int v = atoi(env);
-		if (v >= 1 && v <= 64 && head + (size_t) v * row_bytes <= kLdsPerCu) nch = v;
-	}
+	if (const int v = p->cfg.es_nch; v >= 1 && v <= 64 && head + (size_t) v * row_bytes <= kLdsPerCu) nch = v;
 	if (nch < 1) return MF_OK;
 	p->es_nch = nch;
 	p->es_lds_errors = head + (size_t) nch * row_bytes;

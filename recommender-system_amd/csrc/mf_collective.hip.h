@@ -15,22 +15,32 @@ struct PeerReduceArgs {
 	size_t begin, end;   // element range of this shard's slice (both even)
 };
 
+// All N loads of an element pair are issued before the first add (the loop over the shards is unrolled to kMaxShards with
+// a uniform predicate): a peer load over xGMI takes microseconds, N of them in a row would serialise the launch.
 __global__ void __launch_bounds__(256) peer_allreduce_kernel(PeerReduceArgs a)
 {
 	const size_t stride = (size_t) gridDim.x * 256 * 2;
+	const int n = a.nshards;
 	for (size_t e = a.begin + ((size_t) blockIdx.x * 256 + threadIdx.x) * 2; e < a.end; e += stride) {
 		if (e + 1 < a.end) {
-			double2 v = *reinterpret_cast<const double2 *>(a.buf[0] + e);
-			for (int h = 1; h < a.nshards; ++h) {
-				const double2 w = *reinterpret_cast<const double2 *>(a.buf[h] + e);
-				v.x = v.x + w.x;
-				v.y = v.y + w.y;
-			}
-			for (int h = 0; h < a.nshards; ++h) *reinterpret_cast<double2 *>(a.buf[h] + e) = v;
+			double2 w[kMaxShards];
+#pragma unroll
+			for (int h = 0; h < kMaxShards; ++h)
+				if (h < n) w[h] = *reinterpret_cast<const double2 *>(a.buf[h] + e);
+			double2 v = w[0];
+#pragma unroll
+			for (int h = 1; h < kMaxShards; ++h)
+				if (h < n) {   // shard order: a fixed summation order, so the result is reproducible
+					v.x = v.x + w[h].x;
+					v.y = v.y + w[h].y;
+				}
+#pragma unroll
+			for (int h = 0; h < kMaxShards; ++h)
+				if (h < n) *reinterpret_cast<double2 *>(a.buf[h] + e) = v;
 		} else {
 			double v = a.buf[0][e];
-			for (int h = 1; h < a.nshards; ++h) v = v + a.buf[h][e];
-			for (int h = 0; h < a.nshards; ++h) a.buf[h][e] = v;
+			for (int h = 1; h < n; ++h) v = v + a.buf[h][e];
+			for (int h = 0; h < n; ++h) a.buf[h][e] = v;
 		}
 	}
 }

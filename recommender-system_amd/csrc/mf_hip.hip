@@ -17,6 +17,7 @@
 #include <string>
 #include <vector>
 
+#include "mf_config.hip.h"
 #include "mf_plan.hip.h"
 #include "mf_launch.hip.h"
 #include "mf_build.hip.h"
@@ -91,6 +92,7 @@ static int plan_create_impl(mf_plan **out, const mf_shard *s, const mf_entry *ao
 	p->nnz = s->nnz;
 	p->alpha = s->alpha;
 	p->flags = s->flags;
+	p->cfg = mf_config::from_env();
 
 	int rc = choose_sweep(p);
 	auto fail = [&](int code) {
@@ -128,7 +130,7 @@ static int plan_create_impl(mf_plan **out, const mf_shard *s, const mf_entry *ao
 	// lines where that saves at least a tenth of the lines; caller-owned buffers keep the caller's pitch K.
 	p->ldl = p->ldr = p->K;
 	{
-		const int own = row_pitch(p->K, p->sweep.dma != 0);
+		const int own = row_pitch(p->cfg, p->K, p->sweep.dma != 0);
 		p->ldl = s->users_ext[0] && s->users_ext[1] ? (s->users_pitch ? s->users_pitch : p->K) : own;
 		p->ldr = s->items_ext[0] && s->items_ext[1] ? (s->items_pitch ? s->items_pitch : p->K) : own;
 	}
@@ -175,7 +177,8 @@ int mf_plan_create(mf_plan **out, const mf_shard *s) { return plan_create_impl(o
 int mf_backend_row_pitch(int features)
 {
 	if (features < 1) return MF_ERR_ARGUMENT;
-	return row_pitch(features, sweep_is_dma(features));   // rows are padded for the LDS-DMA forms only
+	const mf_config cfg = mf_config::from_env();
+	return row_pitch(cfg, features, sweep_is_dma(cfg, features));   // rows are padded for the LDS-DMA forms only
 }
 
 int mf_plan_row_pitch(mf_plan *p, int32_t *users_pitch, int32_t *items_pitch)
@@ -223,6 +226,7 @@ void mf_plan_destroy(mf_plan *p)
 	(void) hipFree(p->best_dev);
 	for (int k = 0; k < 2; ++k) {
 		(void) hipFree(p->long_rows[k]);
+		(void) hipFree(p->mid_rows[k]);
 		(void) hipFree(p->short_rows[k]);
 		(void) hipFree(p->seg_row[k]);
 		(void) hipFree(p->seg_beg[k]);
@@ -233,6 +237,8 @@ void mf_plan_destroy(mf_plan *p)
 	}
 	(void) hipFree(p->scratch);
 	if (p->side_stream) (void) hipStreamDestroy(p->side_stream);
+	if (p->mid_stream) (void) hipStreamDestroy(p->mid_stream);
+	if (p->ev_mid_join) (void) hipEventDestroy(p->ev_mid_join);
 	if (p->ev_fork) (void) hipEventDestroy(p->ev_fork);
 	if (p->ev_join) (void) hipEventDestroy(p->ev_join);
 	(void) hipFree(p->lnorm);
@@ -329,7 +335,7 @@ static int iterate_eager(mf_plan *p, int iters)
 		// Both sweeps read only the frozen generation (matFact.c:38-39), so the ordered sums of the item sweep's
 		// extreme rows may run on the side stream UNDER the whole user sweep; they are joined before the flip.
 		// Not when the user sweep has extreme rows of its own: it would reuse the scratch buffer.
-		int rc = launch_sweep(p, 0, 1, /*defer_join=*/p->n_long[1] == 0 && !getenv("MF_SWEEP_NO_DEFER"));
+		int rc = launch_sweep(p, 0, 1, /*defer_join=*/p->n_long[1] == 0 && !p->cfg.no_defer);
 		if (rc != MF_OK) return rc;
 		rc = launch_sweep(p, 1, 1);
 		if (rc != MF_OK) return rc;
@@ -356,11 +362,10 @@ int mf_plan_iterate(mf_plan *p, int iters)
 	// 0.70 -> 0.33 s and inst2 0.47 -> 0.21 s, but inst30-40 (170 entries x K=10) 0.32 -> 0.39 s -- one workgroup
 	// on an otherwise idle chip runs slowly, and two graph-replayed launches per iteration win again.
 	{
-		const char *renv = getenv("MF_RESIDENT");   // "0" disables
 		const size_t need = mf::resident_lds_bytes(p->uc, p->items, p->K, p->nnz);
 		const bool toy = p->uc == p->users_total && p->u0 == 0 && p->uc + p->items <= 1024 && p->uc + p->items > 0 &&
 		                 need <= 60 * 1024 && (double) p->nnz * p->K <= 512.0 && !p->timing && iters >= 8 &&
-		                 !(renv && renv[0] == '0');
+		                 p->cfg.resident;
 		if (toy) {
 			mf::ResidentArgs ra;
 			ra.users = p->uc;
@@ -396,12 +401,10 @@ int mf_plan_iterate(mf_plan *p, int iters)
 			return MF_OK;
 		}
 	}
-	const char *genv = getenv("MF_GRAPH");   // "0" disables
-	const char *gmax = getenv("MF_GRAPH_MAX");   // nnz*K below which iterations are replayed from a graph
-	const bool small = (double) p->nnz * p->K < (gmax ? atof(gmax) : 2e6) && !p->timing && p->n_long[0] == 0 &&
+	const bool small = (double) p->nnz * p->K < p->cfg.graph_max && !p->timing && p->n_long[0] == 0 &&
 	                   p->n_long[1] == 0;
 	constexpr int kGraphIters = 32;
-	if (small && iters >= 4 * kGraphIters && !(genv && genv[0] == '0')) {
+	if (small && iters >= 4 * kGraphIters && p->cfg.graph) {
 		hipGraph_t graph = nullptr;
 		hipGraphExec_t exec = nullptr;
 		const int cur0 = p->cur;
@@ -470,10 +473,8 @@ static int launch_recommend_pass1(mf_plan *p, mf_filter *filt)
 	// vs 50.2, K=30 41.1 vs 37.7.
 	typedef void (*RecFn)(mf::RecMfmaArgs);
 	const bool vec = (p->K & 1) == 0;
-	const char *ares_env = getenv("MF_RECOMMEND_ARES");   // "0" disables the resident-L form (tests, A/B)
-	const char *bdma_env = getenv("MF_RECOMMEND_BDMA");   // "0": stage R chunks through registers (A/B)
-	const bool allow = !(ares_env && ares_env[0] == '0');
-	const bool allow_dma = vec && !(bdma_env && bdma_env[0] == '0');
+	const bool allow = p->cfg.rec_ares;              // MF_RECOMMEND_ARES=0 disables the resident-L form (tests, A/B)
+	const bool allow_dma = vec && p->cfg.rec_bdma;   // MF_RECOMMEND_BDMA=0: stage R chunks through registers (A/B)
 	const size_t static_lds = 8 * 1024, cu_lds = 160 * 1024;   // masks + merge arrays, rounded up
 	int kc = 32;
 	bool ares = false;
@@ -517,8 +518,7 @@ int mf_plan_recommend(mf_plan *p, int32_t *best)
 	if (!p->have_factors) return MF_ERR_STATE;
 	MF_HIP(hipSetDevice(p->device));
 	if (p->uc == 0) return MF_OK;
-	const char *impl = getenv("MF_RECOMMEND_IMPL");   // "mfma" (default) | "exact"
-	const bool use_mfma = !(impl && strcmp(impl, "exact") == 0);
+	const bool use_mfma = !p->cfg.rec_exact;   // MF_RECOMMEND_IMPL=mfma (default) | exact
 	mf::RecArgs ex;
 	ex.users = p->uc;
 	ex.items = p->items;
@@ -722,10 +722,10 @@ int mf_plan_describe(mf_plan *p, char *buf, int buflen)
 	int n;
 	if (p->sweep.dma)
 		n = snprintf(buf, (size_t) buflen,
-		             "sweep_dma_kernel<KT=%d,NPASS=%d> K=%d pitch=%d/%d nch=%d row_bytes=%d lds=%zu long_rows=%d/%d coop_nch=%d",
+		             "sweep_dma_kernel<KT=%d,NPASS=%d> K=%d pitch=%d/%d nch=%d row_bytes=%d lds=%zu long_rows=%d/%d coop_nch=%d double_buffered=%d/%d(nch=%d) mid_rows=%d/%d(nch=%d)",
 		             p->sweep.kt, p->sweep.kt ? (p->K / 2 + 63) / 64 : p->sweep.kpmax, p->K, p->ldl, p->ldr, p->nch, p->sweep.row_bytes,
 		             p->lds_bytes, p->n_long[0] + (p->coop_all[0] ? p->items : 0), p->n_long[1] + (p->coop_all[1] ? p->uc : 0),
-		             p->coop_all[0] || p->coop_all[1] ? p->nch_coop : 0);
+		             p->coop_all[0] || p->coop_all[1] ? p->nch_coop : 0, (int) p->use_db[0], (int) p->use_db[1], p->nch_db, p->n_mid[0], p->n_mid[1], p->nch_mid);
 	else
 		n = snprintf(buf, (size_t) buflen, "sweep_kernel<KT=%d,KPMAX=%d> K=%d nch=%d stride=%d lds=%zu",
 		             p->sweep.kt, p->sweep.kpmax, p->K, p->nch, p->stride, p->lds_bytes);
@@ -738,6 +738,10 @@ int mf_plan_describe(mf_plan *p, char *buf, int buflen)
 			         " iterate=errors+resident-streams(segments=%d x<=%d, %d-column slices of Y in LDS, %d workgroups, lds=%zu/%zu)",
 			         p->es_nseg, p->es_nch, p->res_sw, p->res_nwg, p->es_lds_errors, p->res_lds);
 	}
+	// the environment switches this plan was created under, when any differs from its default (mf_config.hip.h)
+	const std::string cfg = p->cfg.describe();
+	const size_t used = strlen(buf);
+	if (!cfg.empty() && used + 1 < (size_t) buflen) snprintf(buf + used, (size_t) buflen - used, " config{%s}", cfg.c_str());
 	return MF_OK;
 }
 
@@ -804,6 +808,18 @@ int mf_backend_recommend(const mf_problem *pr, const double *L, const double *R,
 	mf_plan_destroy(p);
 	return rc;
 }
+
+#ifdef MF_STAMPS
+// diagnostic build only: read and clear the phase clocks of sweep_dma_kernel (tools/stamps.py)
+int mf_debug_read_stamps(unsigned long long *out8)
+{
+	unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	MF_HIP(hipDeviceSynchronize());
+	MF_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(mf::mf_stamp_buf), sizeof zero));
+	MF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(mf::mf_stamp_buf), zero, sizeof zero));
+	return MF_OK;
+}
+#endif
 
 }  // extern "C"
 

@@ -5,11 +5,10 @@ namespace {
 
 // Slice width (columns) of the LDS-resident streams launch, 0 when a slice of the larger factor does not fit the
 // LDS of a CU beside the waves' buffers or K would need more than eight slices (every slice re-reads the records).
-int resident_slice_width(int K, int yrows_max)
+int resident_slice_width(const mf_config &cfg, int K, int yrows_max)
 {
 	if (K & 1) return 0;
-	const char *force = getenv("MF_ES_SW");   // slice width to try first (A/B)
-	for (int sw : {force ? atoi(force) : 8, 8, 4, 2})
+	for (int sw : {cfg.es_sw ? cfg.es_sw : 8, 8, 4, 2})   // MF_ES_SW: slice width to try first (A/B)
 		if ((sw == 8 || sw == 4 || sw == 2) && (K + sw - 1) / sw <= 8 && (size_t) yrows_max * sw * 8 + mf::kResidentWaves * mf::kResidentWaveLds + 1024 <= kLdsPerCu) return sw;
 	return 0;
 }
@@ -17,10 +16,9 @@ int resident_slice_width(int K, int yrows_max)
 // Row pitch (doubles) of a factor buffer the plan owns: 8K bytes rounded up to whole 128-byte lines when that saves
 // at least a tenth of the lines a gathered row touches on average (rows start wherever 8K * r falls: a row of B bytes
 // touches B/128 + 1 - gcd(B, 128)/128 lines).  LDS-DMA forms only; MF_ROW_PITCH=0 keeps K (A/B).
-int row_pitch(int K, bool dma)
+int row_pitch(const mf_config &cfg, int K, bool dma)
 {
-	const char *env = getenv("MF_ROW_PITCH");
-	if (!dma || (env && env[0] == '0')) return K;
+	if (!dma || !cfg.row_pitch) return K;
 	const int bytes = 8 * K;
 	if (bytes % 128 == 0) return K;
 	int g = 128, b = bytes;
@@ -34,18 +32,16 @@ int row_pitch(int K, bool dma)
 }
 
 // does this K run on an LDS-DMA form of the sweep (even K up to 1024, unless MF_SWEEP_IMPL=reg)?  Mirrors choose_sweep.
-bool sweep_is_dma(int K)
+bool sweep_is_dma(const mf_config &cfg, int K)
 {
-	const char *impl = getenv("MF_SWEEP_IMPL");
-	return !(impl && strcmp(impl, "reg") == 0) && (K & 1) == 0 && K >= 2 && K <= 128 * 8;
+	return !cfg.sweep_reg && (K & 1) == 0 && K >= 2 && K <= 128 * 8;
 }
 
 int choose_sweep(mf_plan *p)
 {
 	const int K = p->K;
-	p->sweep = SweepVariant{nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr};
-	const char *impl = getenv("MF_SWEEP_IMPL");   // "dma" (default) | "reg": register-staged form only
-	const bool allow_dma = !(impl && strcmp(impl, "reg") == 0);
+	p->sweep = SweepVariant{nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+	const bool allow_dma = !p->cfg.sweep_reg;   // MF_SWEEP_IMPL=dma (default) | reg: register-staged form only
 	if (allow_dma)
 		for (const auto &v : kDma)
 			if (v.kt == K) p->sweep = v;
@@ -66,6 +62,7 @@ int choose_sweep(mf_plan *p)
 				break;
 			}
 	if (!p->sweep.fn) return MF_ERR_UNSUPPORTED;
+	if (!p->cfg.sweep_pf) p->sweep.pf = nullptr;   // MF_SWEEP_PF=0 (experiments build): round 2's accumulate form everywhere
 
 	p->stride = K | 1;
 	const size_t row_bytes = p->sweep.dma ? (size_t) p->sweep.row_bytes : (size_t) p->stride * sizeof(double);
@@ -82,34 +79,40 @@ int choose_sweep(mf_plan *p)
 	int nch = 16;
 	if (head + (size_t) nch * row_bytes > kLdsPerCu / 6) nch = std::max(12, fit(kLdsPerCu / 6));
 	nch = std::min(nch, fit(kLdsPerCu));
-	if (const char *env = getenv("MF_SWEEP_NCH")) {
-		const int v = atoi(env);
-		if (v >= 1 && v <= 64 && head + (size_t) v * row_bytes <= kLdsPerCu) nch = v;
-	}
+	if (const int v = p->cfg.sweep_nch; v >= 1 && head + (size_t) v * row_bytes <= kLdsPerCu) nch = v;
 	if (nch < 1) return MF_ERR_UNSUPPORTED;
 	p->nch = nch;
 	p->lds_bytes = head + (size_t) nch * row_bytes;
 	// A sweep over FEW rows (ML100k: 943 x 1682) cannot fill 256 CUs whatever the chunk size; its time is the
 	// longest row's serial chain of chunks, so use the largest chunk there (737 entries: 47 -> 12 chunks).
 	int few = std::max(nch, std::min(64, fit(kLdsPerCu / 2)));
-	if (getenv("MF_SWEEP_NCH")) few = nch;
+	if (p->cfg.sweep_nch) few = nch;
 	p->nch_few = few;
 	p->lds_bytes_few = head + (size_t) few * row_bytes;
 	MF_HIP(raise_lds_limit((const void *) p->sweep.fn, (size_t) (std::max(p->lds_bytes, p->lds_bytes_few))));
+	if (p->sweep.pf) MF_HIP(raise_lds_limit((const void *) p->sweep.pf, (size_t) (std::max(p->lds_bytes, p->lds_bytes_few))));
+	// double-buffered form (few rows per CU: the wave hides its own gather): two tiles of nch_db rows
+	if (p->sweep.db) {
+		int ndb = p->cfg.db_nch > 0 ? p->cfg.db_nch : 16;
+		if (p->cfg.sweep_nch) ndb = p->cfg.sweep_nch;
+		while (ndb > 1 && head + 2 * (size_t) ndb * row_bytes > kLdsPerCu / 2) --ndb;
+		p->nch_db = ndb;
+		p->lds_bytes_db = head + 2 * (size_t) ndb * row_bytes;
+		MF_HIP(raise_lds_limit((const void *) p->sweep.db, p->lds_bytes_db));
+	}
 	// ---- errors + streams iteration (mf_stream.hip.h) for instances whose factors stay in L2 / Infinity Cache: the
 	// two sweeps are then bound by the latency of one wave walking a row chunk by chunk, not by bandwidth.  It costs a
 	// third gather of every entry's row, so it is only chosen while the factors are cache-resident; MF_ITER_MODE=es |
 	// sweeps overrides, MF_ES_MAX_MB moves the limit.
 	p->want_map = false;
-	p->res_sw = resident_slice_width(K, std::max(p->uc, p->items));
+	p->res_sw = resident_slice_width(p->cfg, K, std::max(p->uc, p->items));
 	if (p->sweep.errs && p->nnz > 0) {
 		// Used where the streams launch can keep a slice of Y resident in LDS (mf_resident.hip.h; instML100k 84 -> 39 us
 		// per iteration); MF_ITER_MODE=sweeps keeps the two sweeps, =es asks for it explicitly (same condition).
-		const char *mode = getenv("MF_ITER_MODE");
 		// Not below a few thousand entries: there two graph-replayed single-wave sweeps are quicker than a launch that
 		// first copies a slice of Y into every CU's LDS (inst30-40, 170 entries: 17 vs 20 us per iteration).
-		const bool forced = mode && strcmp(mode, "es") == 0;
-		p->want_map = p->res_sw > 0 && !(mode && strcmp(mode, "sweeps") == 0) && (forced || p->nnz >= 4096);
+		const bool forced = p->cfg.iter_mode == mf_config::kIterEs;
+		p->want_map = p->res_sw > 0 && p->cfg.iter_mode != mf_config::kIterSweeps && (forced || p->nnz >= 4096);
 	}
 	return MF_OK;
 }
@@ -124,6 +127,7 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 	a.nch = p->nch;
 	a.stride = p->stride;
 	a.seed = seed;
+	a.prio_len = p->prio_len[kind];
 	a.c2 = p->alpha * 2;
 	const int nxt = p->cur ^ 1;
 	a.ldx = kind == 0 ? p->ldr : p->ldl;
@@ -154,11 +158,19 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 	// "few rows": the launch cannot fill the chip whatever the chunk size, its time is the longest row's serial chain
 	// of chunks -> the largest chunk.  Only below ~2048 rows: at 3952 rows (the cfg3 item sweep) the large chunk's LDS
 	// footprint cost more occupancy than it saved (item sweep 0.189 -> 0.123 ms with the ordinary chunk).
-	const bool few_rows = a.nrows < (getenv("MF_SWEEP_FEW") ? atoi(getenv("MF_SWEEP_FEW")) : 2048);
+	const bool few_rows = a.nrows < p->cfg.sweep_few;
 	const bool coop = p->coop_all[kind];
+	const bool db = !coop && p->use_db[kind];
 	if (few_rows) a.nch = coop ? p->nch_coop : p->nch_few;
-	const size_t lds = coop ? p->lds_bytes_coop : (few_rows ? p->lds_bytes_few : p->lds_bytes);
-	const SweepFn fn = coop ? p->sweep.coop : p->sweep.fn;
+	if (db) a.nch = p->nch_db;
+	const size_t lds = coop ? p->lds_bytes_coop : db ? p->lds_bytes_db : (few_rows ? p->lds_bytes_few : p->lds_bytes);
+	// Accumulate form of the single-wave launch.  Up to kPfRows rows: the form whose phases keep their LDS reads in flight
+	// and whose gather issue is lean -- what a wave walking a long row alone is bound by (cfg3 uniform 0.224 -> 0.201 ms,
+	// power-law 0.367 -> 0.350, a lone 5993-entry row 1.02 -> 0.78 ms).  Larger launches are never bound by one wave and
+	// keep round 2's form (cfg4 user sweep, 1e6 rows: 11.45 vs 11.60 ms).
+	constexpr int kPfRows = 262144;
+	const SweepFn single = p->sweep.pf && p->n_short[kind] <= kPfRows && a.nrows <= kPfRows ? p->sweep.pf : p->sweep.fn;
+	const SweepFn fn = coop ? p->sweep.coop : db ? p->sweep.db : single;
 	const int block = coop ? mf::kCoopWaves * mf::kWave : mf::kWave;
 	const int grid = std::min(a.nrows, 1 << 20);
 	TimedLaunch t{};
@@ -174,6 +186,7 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 		// beside the sweep of the other rows (schedule below)
 		mf::SweepArgs b = a;
 		b.nrows = p->n_seg[kind];
+		b.prio_len = 0;
 		b.rowlist = nullptr;
 		b.nch = p->nch_prod;
 		b.seg_row = p->seg_row[kind];
@@ -202,8 +215,7 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 		// Schedule (MF_SWEEP_SUM_ORDER): "after" (default) -- products kernel and ordered sums on the side stream
 		// while the remaining rows run on the main stream; "under" -- products first on the main stream, then the
 		// ordered sums on the side stream under the sweep of the remaining rows.
-		const char *ord = getenv("MF_SWEEP_SUM_ORDER");
-		const bool under = ord && strcmp(ord, "under") == 0;
+		const bool under = p->cfg.sum_under;
 		hipStream_t prod_stream = under ? p->stream : p->side_stream;
 		if (!under) {
 			MF_HIP(hipEventRecord(p->ev_fork, p->stream));
@@ -215,9 +227,24 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 			MF_HIP(hipEventRecord(p->ev_fork, p->stream));
 			MF_HIP(hipStreamWaitEvent(p->side_stream, p->ev_fork, 0));
 		}
-		MF_HIP(hipLaunchKernel((const void *) mf::ordered_sum_kernel, dim3(o.nrows * o.nslices), dim3(mf::kWave), oargs,
+		MF_HIP(hipLaunchKernel(p->cfg.os_dpp ? (const void *) mf::ordered_sum_kernel<true> : (const void *) mf::ordered_sum_kernel<false>,
+		                       dim3(o.nrows * o.nslices), dim3(mf::kWave), oargs,
 		                       p->lds_bytes_osum, p->side_stream));
 		MF_HIP(hipEventRecord(p->ev_join, p->side_stream));
+		if (p->n_mid[kind] > 0) {
+			// mid-length rows: double-buffered form with the large chunk, on its own stream beside everything else
+			mf::SweepArgs m = a;
+			m.nrows = p->n_mid[kind];
+			m.rowlist = p->mid_rows[kind];
+			m.nch = p->nch_mid;
+			void *margs[] = {&m};
+			MF_HIP(hipStreamWaitEvent(p->mid_stream, p->ev_fork, 0));
+			if (p->mid_coop)
+				MF_HIP(hipLaunchKernel((const void *) p->sweep.coop, dim3(m.nrows), dim3(mf::kCoopWaves * mf::kWave), margs, p->lds_bytes_mid, p->mid_stream));
+			else
+			MF_HIP(hipLaunchKernel((const void *) p->sweep.db, dim3(m.nrows), dim3(mf::kWave), margs, p->lds_bytes_mid, p->mid_stream));
+			MF_HIP(hipEventRecord(p->ev_mid_join, p->mid_stream));
+		}
 		a.nrows = p->n_short[kind];
 		a.rowlist = p->short_rows[kind];
 		a.nch = p->nch;   // the extreme rows are gone: the occupancy-friendly chunk size is right again
@@ -225,9 +252,14 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 			a.nch = p->nch_coop;
 			MF_HIP(hipLaunchKernel((const void *) p->sweep.coop, dim3(std::min(a.nrows, 1 << 20)),
 			                       dim3(mf::kCoopWaves * mf::kWave), args, p->lds_bytes_coop, p->stream));
+		} else if (a.nrows > 0 && db) {
+			a.nch = p->nch_db;
+			MF_HIP(hipLaunchKernel((const void *) p->sweep.db, dim3(std::min(a.nrows, 1 << 20)), dim3(mf::kWave), args,
+			                       p->lds_bytes_db, p->stream));
 		} else if (a.nrows > 0)
-			MF_HIP(hipLaunchKernel((const void *) p->sweep.fn, dim3(std::min(a.nrows, 1 << 20)), dim3(mf::kWave), args,
+			MF_HIP(hipLaunchKernel((const void *) single, dim3(std::min(a.nrows, 1 << 20)), dim3(mf::kWave), args,
 			                       p->lds_bytes, p->stream));
+		if (p->n_mid[kind] > 0) MF_HIP(hipStreamWaitEvent(p->stream, p->ev_mid_join, 0));
 		if (defer_join)
 			p->join_pending = true;
 		else

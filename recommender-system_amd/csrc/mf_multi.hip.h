@@ -15,7 +15,9 @@
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types and enums only: the library itself is dlopen()ed on first use
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <thread>
 
 namespace {
@@ -53,8 +55,9 @@ struct Rccl {
 Rccl g_rccl;
 
 struct MultiTiming {
-	double setup_s = 0, iterate_s = 0, recommend_s = 0;
-	int shards = 0, reducer = 0, sliced = 0;
+	double setup_s = 0, iterate_s = 0, recommend_s = 0, enqueue_s = 0;
+	int shards = 0, reducer = 0, sliced = 0, threads = 0;
+	long long entry_passes = 0;   // passes of the host over all nnz entries during set-up (count, scatter)
 };
 MultiTiming g_multi_timing;
 
@@ -87,6 +90,7 @@ int slice_entries(const mf_entry *entries, int64_t nnz, bool by_col, bool sorted
 	} catch (const std::bad_alloc &) {
 		return MF_ERR_NO_MEMORY;
 	}
+	g_multi_timing.entry_passes++;   // the stable scatter reads every entry once more
 	const int nkeys = (int) cnt.size() - 1;
 	std::vector<signed char> owner((size_t) std::max(nkeys, 1));
 	for (int g = 0; g < ndev; ++g)
@@ -111,6 +115,7 @@ int count_entries(const mf_problem *pr, bool by_col, std::vector<int64_t> &cnt, 
 	}
 	sorted = true;
 	int prev = -1;
+	g_multi_timing.entry_passes++;
 	for (int64_t n = 0; n < pr->nnz; ++n) {
 		const mf_entry &e = pr->entries[n];
 		if (e.row < 0 || e.row >= pr->users || e.col < 0 || e.col >= pr->items) return MF_ERR_ARGUMENT;
@@ -181,75 +186,189 @@ struct ShardSet {
 	}
 };
 
-// One sharded factorisation over plans that already hold their entries and initial factors.  Per iteration and
-// shard g:   B sweep (shard 0 seeds from the old factor, the others from zero: matFact-mpi.c:187)  -> ev_items[g]
-//            A sweep on the SAME stream (needs no communication)            || reduce of B_next on red_stream[g]
-//            flip once every reduce has finished.
-// The reduce runs on its own high-priority stream, so it overlaps the A sweep (the MPI variant's
-// MPI_Iallreduce ... MPI_Waitall, matFact-mpi.c:207-209).
-int iterate_shards(ShardSet &ss, int iters, size_t nb, bool use_rccl)
-{
-	const int ndev = (int) ss.plan.size();
-	for (int it = 0; it < iters; ++it) {
-		for (int g = 0; g < ndev; ++g) {
-			mf_plan *p = ss.plan[(size_t) g];
-			int rc = mf_plan_sweep_items(p, g == 0);
-			if (rc != MF_OK) return rc;
-			MF_HIP(hipEventRecord(ss.ev_items[(size_t) g], p->stream));
-			rc = mf_plan_sweep_users(p);
-			if (rc != MF_OK) return rc;
+// A reusable barrier between the per-shard host threads (C++17: no std::barrier).
+struct HostBarrier {
+	std::mutex mu;
+	std::condition_variable cv;
+	int n, waiting = 0;
+	unsigned long long generation = 0;
+	explicit HostBarrier(int count) : n(count) {}
+	void arrive_and_wait()
+	{
+		std::unique_lock<std::mutex> lk(mu);
+		const unsigned long long gen = generation;
+		if (++waiting == n) {
+			waiting = 0;
+			++generation;
+			cv.notify_all();
+		} else
+			cv.wait(lk, [&] { return generation != gen; });
+	}
+};
+
+// What one shard enqueues per iteration.  Phase 1: B sweep (shard 0 seeds from the old factor, the others from zero:
+// matFact-mpi.c:187), ev_items[g], A sweep on the same stream (needs no communication).  Phase 2, once EVERY shard has
+// recorded its ev_items: the reduce of B_next on red_stream[g] (its own high-priority stream, so it overlaps the A
+// sweep -- the MPI_Iallreduce ... MPI_Waitall of matFact-mpi.c:207-209), ev_red[g].  Phase 3, once every ev_red is
+// recorded: the plan's stream waits for the reduces that wrote into its buffer, then flips.
+//
+// hipStreamWaitEvent captures the event's LATEST record at the time of the call, so a wait on another shard's event must
+// be enqueued after that shard's thread has recorded it for this iteration: the phases are separated by host barriers
+// when the shards are driven by one thread each (threads = true), and by program order when one thread drives them all.
+struct ShardLoop {
+	ShardSet &ss;
+	size_t nb;
+	bool use_rccl;
+	int ndev;
+	int phase1(int g)
+	{
+		mf_plan *p = ss.plan[(size_t) g];
+		int rc = mf_plan_sweep_items(p, g == 0);   // sets the device
+		if (rc != MF_OK) return rc;
+		MF_HIP(hipEventRecord(ss.ev_items[(size_t) g], p->stream));
+		return mf_plan_sweep_users(p);
+	}
+	int phase2_peer(int g)
+	{
+		MF_HIP(hipSetDevice(ss.plan[(size_t) g]->device));
+		// device g sums slice g of every shard's buffer: it needs every shard's B sweep
+		for (int h = 0; h < ndev; ++h) MF_HIP(hipStreamWaitEvent(ss.red_stream[(size_t) g], ss.ev_items[(size_t) h], 0));
+		mf::PeerReduceArgs a;
+		a.nshards = ndev;
+		for (int h = 0; h < ndev; ++h) a.buf[h] = ss.plan[(size_t) h]->Rbuf[ss.plan[(size_t) h]->cur ^ 1];
+		a.begin = ((nb / 2) * (size_t) g / (size_t) ndev) * 2;
+		a.end = g == ndev - 1 ? nb : ((nb / 2) * (size_t) (g + 1) / (size_t) ndev) * 2;
+		if (a.end > a.begin) {
+			const size_t pairs = (a.end - a.begin + 1) / 2;
+			const unsigned grid = (unsigned) std::min<size_t>((pairs + 255) / 256, 2048);
+			hipLaunchKernelGGL(mf::peer_allreduce_kernel, dim3(grid), dim3(256), 0, ss.red_stream[(size_t) g], a);
+			MF_HIP(hipGetLastError());
 		}
-		if (use_rccl) {
-			// one group call: a single thread drives every device's rank of the communicator
-			for (int g = 0; g < ndev; ++g) {
-				MF_HIP(hipSetDevice(ss.plan[(size_t) g]->device));
-				MF_HIP(hipStreamWaitEvent(ss.red_stream[(size_t) g], ss.ev_items[(size_t) g], 0));
-			}
-			ncclResult_t nrc = g_rccl.GroupStart();
-			for (int g = 0; g < ndev && nrc == ncclSuccess; ++g) {
-				mf_plan *p = ss.plan[(size_t) g];
-				double *buf = p->Rbuf[p->cur ^ 1];
-				nrc = g_rccl.AllReduce(buf, buf, nb, ncclDouble, ncclSum, ss.comm[(size_t) g], ss.red_stream[(size_t) g]);
-			}
-			const ncclResult_t erc = g_rccl.GroupEnd();
-			if (nrc == ncclSuccess) nrc = erc;
-			if (nrc != ncclSuccess) {
-				g_last_hip_error = std::string("ncclAllReduce: ") + g_rccl.GetErrorString(nrc);
-				return MF_ERR_HIP;
-			}
-		} else {
-			for (int g = 0; g < ndev; ++g) {
-				MF_HIP(hipSetDevice(ss.plan[(size_t) g]->device));
-				for (int h = 0; h < ndev; ++h)
-					MF_HIP(hipStreamWaitEvent(ss.red_stream[(size_t) g], ss.ev_items[(size_t) h], 0));
-				mf::PeerReduceArgs a;
-				a.nshards = ndev;
-				for (int h = 0; h < ndev; ++h) a.buf[h] = ss.plan[(size_t) h]->Rbuf[ss.plan[(size_t) h]->cur ^ 1];
-				a.begin = ((nb / 2) * (size_t) g / (size_t) ndev) * 2;
-				a.end = g == ndev - 1 ? nb : ((nb / 2) * (size_t) (g + 1) / (size_t) ndev) * 2;
-				if (a.end > a.begin) {
-					const size_t pairs = (a.end - a.begin + 1) / 2;
-					const unsigned grid = (unsigned) std::min<size_t>((pairs + 255) / 256, 2048);
-					hipLaunchKernelGGL(mf::peer_allreduce_kernel, dim3(grid), dim3(256), 0, ss.red_stream[(size_t) g], a);
-					MF_HIP(hipGetLastError());
-				}
-			}
+		MF_HIP(hipEventRecord(ss.ev_red[(size_t) g], ss.red_stream[(size_t) g]));
+		return MF_OK;
+	}
+	int phase2_rccl_wait(int g)
+	{
+		MF_HIP(hipSetDevice(ss.plan[(size_t) g]->device));
+		MF_HIP(hipStreamWaitEvent(ss.red_stream[(size_t) g], ss.ev_items[(size_t) g], 0));   // RCCL orders the ranks itself
+		return MF_OK;
+	}
+	int phase2_rccl_reduce(int g)
+	{
+		mf_plan *p = ss.plan[(size_t) g];
+		double *buf = p->Rbuf[p->cur ^ 1];
+		const ncclResult_t nrc = g_rccl.AllReduce(buf, buf, nb, ncclDouble, ncclSum, ss.comm[(size_t) g], ss.red_stream[(size_t) g]);
+		if (nrc != ncclSuccess) {
+			g_last_hip_error = std::string("ncclAllReduce: ") + g_rccl.GetErrorString(nrc);
+			return MF_ERR_HIP;
 		}
-		for (int g = 0; g < ndev; ++g) {
-			MF_HIP(hipSetDevice(ss.plan[(size_t) g]->device));
-			MF_HIP(hipEventRecord(ss.ev_red[(size_t) g], ss.red_stream[(size_t) g]));
-		}
+		return MF_OK;
+	}
+	int phase2_rccl_record(int g)
+	{
+		MF_HIP(hipSetDevice(ss.plan[(size_t) g]->device));
+		MF_HIP(hipEventRecord(ss.ev_red[(size_t) g], ss.red_stream[(size_t) g]));
+		return MF_OK;
+	}
+	int phase3(int g)
+	{
+		mf_plan *p = ss.plan[(size_t) g];
+		MF_HIP(hipSetDevice(p->device));
 		// the peer reduce of device h writes its slice into EVERY shard's buffer: wait for all of them; RCCL's
 		// all-reduce on my stream completes only when my buffer is final: my own event is enough
-		for (int g = 0; g < ndev; ++g) {
-			mf_plan *p = ss.plan[(size_t) g];
-			MF_HIP(hipSetDevice(p->device));
-			for (int h = 0; h < ndev; ++h)
-				if (!use_rccl || h == g) MF_HIP(hipStreamWaitEvent(p->stream, ss.ev_red[(size_t) h], 0));
-			mf_plan_flip(p);
-		}
+		for (int h = 0; h < ndev; ++h)
+			if (!use_rccl || h == g) MF_HIP(hipStreamWaitEvent(p->stream, ss.ev_red[(size_t) h], 0));
+		return mf_plan_flip(p);
 		// (the next iteration's reduce on red_stream[g] waits for every shard's next B sweep, which its main stream
 		// enqueues behind the joins above: no reduce can run ahead of an unfinished one)
+	}
+};
+
+// One sharded factorisation over plans that already hold their entries and initial factors.  threads = true (default):
+// one host thread per shard enqueues that shard's work, so the ~2N+6 runtime calls a shard needs per iteration (N event
+// waits before its reduce, N before its flip) are issued concurrently instead of N(2N+6) in a row from one thread -- at
+// N = 8 about 180 calls per iteration against a 3 ms iteration of the cfg4 shard.  enqueue_s returns the time the
+// slowest thread spent enqueueing (everything but the final synchronize).
+int iterate_shards(ShardSet &ss, int iters, size_t nb, bool use_rccl, bool threads, double *enqueue_s)
+{
+	const int ndev = (int) ss.plan.size();
+	ShardLoop loop{ss, nb, use_rccl, ndev};
+	if (enqueue_s) *enqueue_s = 0.0;
+	if (!threads || ndev == 1) {
+		const double t0 = now_s();
+		for (int it = 0; it < iters; ++it) {
+			for (int g = 0; g < ndev; ++g) {
+				const int rc = loop.phase1(g);
+				if (rc != MF_OK) return rc;
+			}
+			if (use_rccl) {
+				// one group call: a single thread drives every device's rank of the communicator
+				for (int g = 0; g < ndev; ++g) {
+					const int rc = loop.phase2_rccl_wait(g);
+					if (rc != MF_OK) return rc;
+				}
+				ncclResult_t nrc = g_rccl.GroupStart();
+				int rc = MF_OK;
+				for (int g = 0; g < ndev && nrc == ncclSuccess && rc == MF_OK; ++g) rc = loop.phase2_rccl_reduce(g);
+				const ncclResult_t erc = g_rccl.GroupEnd();
+				if (rc != MF_OK) return rc;
+				if (nrc == ncclSuccess) nrc = erc;
+				if (nrc != ncclSuccess) {
+					g_last_hip_error = std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(nrc);
+					return MF_ERR_HIP;
+				}
+				for (int g = 0; g < ndev; ++g) {
+					rc = loop.phase2_rccl_record(g);
+					if (rc != MF_OK) return rc;
+				}
+			} else
+				for (int g = 0; g < ndev; ++g) {
+					const int rc = loop.phase2_peer(g);
+					if (rc != MF_OK) return rc;
+				}
+			for (int g = 0; g < ndev; ++g) {
+				const int rc = loop.phase3(g);
+				if (rc != MF_OK) return rc;
+			}
+		}
+		if (enqueue_s) *enqueue_s = now_s() - t0;
+	} else {
+		HostBarrier bar(ndev);
+		std::vector<int> failed((size_t) ndev, MF_OK);
+		std::vector<double> spent((size_t) ndev, 0.0);
+		std::atomic<int> any_failed{0};
+		// a thread that fails keeps arriving at the barriers (skipping its work) so nobody waits for it forever
+		const int rc = for_each_shard(ndev, [&](int g) -> int {
+			const double t0 = now_s();
+			int mine = MF_OK;
+			auto run = [&](int r) {
+				if (r != MF_OK && mine == MF_OK) {
+					mine = r;
+					any_failed.store(1);
+				}
+			};
+			for (int it = 0; it < iters; ++it) {
+				if (!any_failed.load()) run(loop.phase1(g));
+				bar.arrive_and_wait();   // every ev_items of this iteration is recorded
+				if (!any_failed.load()) {
+					if (use_rccl) {      // one thread per rank, no group: each rank's call may block until its peers arrive
+						run(loop.phase2_rccl_wait(g));
+						if (mine == MF_OK) run(loop.phase2_rccl_reduce(g));
+						if (mine == MF_OK) run(loop.phase2_rccl_record(g));
+					} else
+						run(loop.phase2_peer(g));
+				}
+				bar.arrive_and_wait();   // every ev_red of this iteration is recorded
+				if (!any_failed.load()) run(loop.phase3(g));
+				// (no barrier here: the next wait on one of my events comes after the next iteration's first barrier, which
+				// I reach only after re-recording it)
+			}
+			spent[(size_t) g] = now_s() - t0;
+			failed[(size_t) g] = mine;
+			return mine;
+		});
+		if (rc != MF_OK) return rc;
+		if (enqueue_s) *enqueue_s = *std::max_element(spent.begin(), spent.end());
 	}
 	for (int g = 0; g < ndev; ++g) {
 		const int rc = mf_plan_synchronize(ss.plan[(size_t) g]);
@@ -275,19 +394,26 @@ int mf_backend_multi_last_timing(double *setup_s, double *iterate_s, double *rec
 	return MF_OK;
 }
 
+int mf_backend_multi_last_counters(double *enqueue_s, int64_t *entry_passes, int *host_threads)
+{
+	if (enqueue_s) *enqueue_s = g_multi_timing.enqueue_s;
+	if (entry_passes) *entry_passes = g_multi_timing.entry_passes;
+	if (host_threads) *host_threads = g_multi_timing.threads;
+	return MF_OK;
+}
+
 int mf_backend_run_multi(const mf_problem *pr, double *L, double *R, int32_t *best, const int *devices, int ndev)
 {
 	if (!pr || !L || !R || !devices || ndev < 1 || ndev > mf::kMaxShards || pr->users < 0 || pr->items < 0 ||
 	    pr->features < 1 || pr->nnz < 0 || pr->iters < 0 || (pr->nnz > 0 && !pr->entries))
 		return MF_ERR_ARGUMENT;
-	const char *force = getenv("MF_MULTI_FORCE");   // "1": take the sharded path even for one shard (tests)
-	if (ndev == 1 && !(force && force[0] == '1')) return mf_backend_run(pr, L, R, best, devices[0]);
+	const mf_config cfg = mf_config::from_env();
+	if (ndev == 1 && !cfg.multi_force) return   /* MF_MULTI_FORCE=1: the sharded path even for one shard (tests) */ mf_backend_run(pr, L, R, best, devices[0]);
 	const int total = mf_backend_device_count();
 	if (total <= 0) return MF_ERR_NO_DEVICE;
 	for (int g = 0; g < ndev; ++g)
 		if (devices[g] < 0 || devices[g] >= total) return MF_ERR_NO_DEVICE;
-	const char *red = getenv("MF_MULTI_REDUCE");    // "peer" (default) | "rccl"
-	const bool use_rccl = red && strcmp(red, "rccl") == 0;
+	const bool use_rccl = cfg.multi_rccl;   // MF_MULTI_REDUCE=peer (default) | rccl
 	const int U = pr->users, I = pr->items, K = pr->features;
 	const double t_start = now_s();
 	g_multi_timing = MultiTiming();
@@ -374,7 +500,8 @@ int mf_backend_run_multi(const mf_problem *pr, double *L, double *R, int32_t *be
 	g_multi_timing.setup_s = t_setup - t_start;
 
 	// the replicated buffers are summed whole, padding included (every plan pads the same way: zeros)
-	rc = iterate_shards(ss, pr->iters, (size_t) nrows_b * (size_t) ss.plan[0]->ldr, use_rccl);
+	g_multi_timing.threads = cfg.multi_threads && ndev > 1 ? ndev : 1;
+	rc = iterate_shards(ss, pr->iters, (size_t) nrows_b * (size_t) ss.plan[0]->ldr, use_rccl, cfg.multi_threads, &g_multi_timing.enqueue_s);
 	if (rc != MF_OK) return rc;
 	const double t_iter = now_s();
 	g_multi_timing.iterate_s = t_iter - t_setup;

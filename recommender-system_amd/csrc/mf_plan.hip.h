@@ -42,12 +42,14 @@ struct SweepVariant {
 	SweepFn coop;   // row-cooperative form for tiny sweeps (compile-time-K DMA variants only)
 	SweepFn prod;   // products form for segments of extreme rows (all DMA variants)
 	SweepFn errs;   // errors form: e_n per entry of a segment (all DMA variants; mf_stream.hip.h)
+	SweepFn db;     // intra-wave double-buffered form for launches of few rows (all DMA variants)
+	SweepFn pf;     // accumulate form with the LDS reads of phases A / B kept in flight (compile-time-K DMA variants)
 };
 
 template <int KT, int KP>
 constexpr SweepVariant variant()
 {
-	return SweepVariant{mf::sweep_kernel<KT, KP>, KT, KP, 0, 0, 0, nullptr, nullptr, nullptr};
+	return SweepVariant{mf::sweep_kernel<KT, KP>, KT, KP, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
 }
 
 template <int KT>
@@ -56,7 +58,9 @@ constexpr SweepVariant dma_variant()
 	return SweepVariant{mf::sweep_dma_kernel<KT, mf::DmaGeom<KT>::kPasses>, KT, 0, 1, mf::DmaGeom<KT>::kStride,
 	                    mf::DmaGeom<KT>::kXsBytes, mf::sweep_coop_kernel<KT>,
 	                    mf::sweep_dma_kernel<KT, mf::DmaGeom<KT>::kPasses, mf::kSweepProducts>,
-	                    mf::sweep_dma_kernel<KT, mf::DmaGeom<KT>::kPasses, mf::kSweepErrors>};
+	                    mf::sweep_dma_kernel<KT, mf::DmaGeom<KT>::kPasses, mf::kSweepErrors>,
+	                    mf::sweep_db_kernel<KT, mf::DmaGeom<KT>::kPasses>,
+	                    mf::sweep_dma_kernel<KT, mf::DmaGeom<KT>::kPasses, mf::kSweepAccumulate, 8>};
 }
 
 // run-time even K <= 128 * NPASS through the LDS-DMA kernel (row_bytes / xs_bytes filled in per plan)
@@ -64,7 +68,8 @@ template <int NPASS>
 constexpr SweepVariant dma_generic_variant()
 {
 	return SweepVariant{mf::sweep_dma_kernel<0, NPASS>, 0, NPASS, 1, 0, 0, nullptr,
-	                    mf::sweep_dma_kernel<0, NPASS, mf::kSweepProducts>, mf::sweep_dma_kernel<0, NPASS, mf::kSweepErrors>};
+	                    mf::sweep_dma_kernel<0, NPASS, mf::kSweepProducts>, mf::sweep_dma_kernel<0, NPASS, mf::kSweepErrors>,
+	                    mf::sweep_db_kernel<0, NPASS>, nullptr};
 }
 
 // K-specialised instances for the K of the bundled samples and of the BASELINE configs, then generic ones.
@@ -96,6 +101,7 @@ struct TimedLaunch {
 }  // namespace
 
 struct mf_plan {
+	mf_config cfg;   // the environment switches, read once at creation (mf_config.hip.h)
 	int device = 0;
 	int users_total = 0, items = 0, K = 0;
 	int u0 = 0, uc = 0;
@@ -148,12 +154,28 @@ struct mf_plan {
 	size_t lds_bytes = 0;
 	int nch_few = 0;            // chunk size when a sweep has too few rows to fill the chip (see choose_sweep)
 	size_t lds_bytes_few = 0;
+	int nch_db = 0;             // chunk size and LDS request (two tiles) of the double-buffered form
+	size_t lds_bytes_db = 0;
+	bool use_db[2] = {false, false};   // the sweep's single-wave launch takes the double-buffered form (plan_row_schedule)
+	// mid-length rows of a skewed sweep (below the extreme threshold, far above the mean): their own launch of the
+	// double-buffered form with a LARGE chunk on a second side stream -- a wave that keeps 48 rows in flight gets a
+	// matching share of its CU's gather rate instead of 1/11 of it, so the walk of the longest remaining row no longer
+	// sets the sweep's time
+	int *mid_rows[2] = {nullptr, nullptr};
+	int n_mid[2] = {0, 0};
+	int nch_mid = 0;
+	size_t lds_bytes_mid = 0;
+	bool mid_coop = false;   // the mid-length rows go through the row-cooperative kernel (8 waves per row) instead
+	hipStream_t mid_stream = nullptr;
+	hipEvent_t ev_mid_join = nullptr;
 	int max_row_len[2] = {0, 0}; // longest column (item sweep) / longest user row (user sweep)
+	int prio_len[2] = {0, 0};    // rows at least this long run at raised wave priority in the single-wave launch (0: none)
 	// skew-aware split of a sweep with many rows: rows whose serial walk would dominate the launch go to the
 	// row-cooperative kernel on a side stream, the others stay on the single-wave kernel
 	int *long_rows[2] = {nullptr, nullptr}, *short_rows[2] = {nullptr, nullptr};
 	bool lpt[2] = {false, false};   // short_rows[kind] = ALL rows, longest first: the order of a sweep without extreme rows
 	int n_long[2] = {0, 0}, n_short[2] = {0, 0};
+	int long_len[2] = {0, 0};   // a row at least this long is on the extreme-row path (when n_long > 0)
 	// extreme rows of LARGE sweeps: 256-entry segments -> scaled rows in `scratch` -> ordered sum
 	int n_seg[2] = {0, 0};
 	int *seg_row[2] = {nullptr, nullptr}, *seg_beg[2] = {nullptr, nullptr}, *seg_end[2] = {nullptr, nullptr};

@@ -36,6 +36,7 @@ struct SweepArgs {
 	int stride;   // LDS row stride in doubles (odd)
 	int ldx, ldy; // row pitch of X and of Y in doubles (>= K: rows of 8K bytes padded to whole 128-byte lines, mf_plan)
 	int seed;     // 1: accumulate onto X_old, 0: onto zero
+	int prio_len; // rows of at least this many entries run at raised wave priority (0: none)
 	double c2;    // alpha * 2
 	const int *__restrict__ ptr;
 	const int *__restrict__ idx;
@@ -181,6 +182,36 @@ constexpr int kSliceShift = kSliceCols == 8 ? 3 : 4;  // log2(kSliceCols)
 constexpr int kPieceShift = kSliceShift - 1;
 static_assert(kSliceCols == 8 || kSliceCols == 16, "slice width");
 
+// Phase A / phase B with the LDS reads kept IN FLIGHT (PF steps / PB entries ahead) instead of the two steps per round
+// trip hipcc schedules by itself (it aims at 64 registers): one wave walking a long row alone -- the tail of every launch of
+// a few thousand rows -- is bound by the LDS latency of these reads, 25 round trips per chunk at K=100, not by the chain of
+// dependent adds.  Same operations in the same order: same bits.  Empty asm statements with a memory clobber keep the reads where they
+// are written (a sched_barrier does not: the loads are hoisted above it before the machine scheduler runs).
+template <int Q, int PF>
+__device__ __forceinline__ double phase_a_dot_pipelined(const double2 *t2, const double2 *xs)
+{
+	double2 t[PF], x[PF];
+#pragma unroll
+	for (int i = 0; i < PF; ++i)
+		if (i < Q) {
+			t[i] = t2[i];
+			x[i] = xs[i];
+		}
+	double dot = 0.0;
+#pragma unroll
+	for (int q = 0; q < Q; ++q) {
+		const double2 tt = t[q % PF], xx = x[q % PF];
+		if (q + PF < Q) {
+			t[q % PF] = t2[q + PF];
+			x[q % PF] = xs[q + PF];
+		}
+		asm volatile("" ::: "memory");   // pins the issue order: the reads above go out before the arithmetic below
+		dot = dot + xx.x * tt.x;
+		dot = dot + xx.y * tt.y;
+	}
+	return dot;
+}
+
 // KT > 0: K is a compile-time constant (phase A fully unrolled).  KT == 0: any even K up to 128*NPASS at run
 // time (phase A unrolled by four) -- same data movement, so an unusual K does not fall back to the
 // register-staged kernel.
@@ -190,7 +221,16 @@ static_assert(kSliceCols == 8 || kSliceCols == 16, "slice width");
 // parallel, so a row rated by every user costs a chip-wide pass plus one serial chain of adds.
 // MODE: 0 accumulate (the sweep), 1 products (extreme rows), 2 errors (first half of the errors + streams iteration)
 constexpr int kSweepAccumulate = 0, kSweepProducts = 1, kSweepErrors = 2;
-template <int KT, int NPASS, int MODE = kSweepAccumulate>
+#ifdef MF_STAMPS
+// diagnostic build only (tools/stamps.py): shader-clock totals of the phases of the rows of at least 1024 entries --
+// [0] rows, [1] chunks, [2] gather issue, [3] landing wait, [4] phase A, [5] phase B, [6] whole row
+__device__ unsigned long long mf_stamp_buf[8];
+#define MF_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define MF_STAMP(var)
+#endif
+
+template <int KT, int NPASS, int MODE = kSweepAccumulate, int PF = 0>
 __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 {
 	constexpr bool PRODUCTS = MODE == kSweepProducts, ERRORS = MODE == kSweepErrors, SEGMENTS = MODE != kSweepAccumulate;
@@ -213,7 +253,20 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 		const int beg = SEGMENTS ? a.seg_beg[it] : a.ptr[r];
 		const int end = SEGMENTS ? a.seg_end[it] : a.ptr[r + 1];
 		const double2 *__restrict__ xrow2 = reinterpret_cast<const double2 *>(a.X_old + (size_t) r * a.ldx);
+		// A wave walking a long row is bound by its own instruction stream and shares its SIMD's issue slots with the
+		// waves of short rows; it is also what the launch ends on.  Rows of at least prio_len entries run at raised
+		// priority (issue arbitration is by priority, then age), the others at the default.
+		if (a.prio_len > 0) {
+			if (end - beg >= a.prio_len)
+				__builtin_amdgcn_s_setprio(3);
+			else
+				__builtin_amdgcn_s_setprio(0);
+		}
 
+#ifdef MF_STAMPS
+		unsigned long long st_issue = 0, st_wait = 0, st_a = 0, st_b = 0, st_chunks = 0;
+#endif
+		MF_STAMP(t_row0);
 		double2 acc[NP];
 #pragma unroll
 		for (int p = 0; p < NP; ++p) {
@@ -247,6 +300,7 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 			// ---- stage.  Short rows (K <= 62) are gathered SEVERAL per instruction: lane -> (row lane / PS, piece
 			// lane % PS) with PS = the tile row stride in pieces (P, or P + 1 when P is even: that lane is the padding
 			// and stays off), 12 rows at K=10, 5 at K=20 -- instead of one instruction with five active lanes per row.
+			MF_STAMP(t_s0);
 			constexpr bool kMultiRow = KT > 0 && ((KT / 2) | 1) <= 32;
 			if constexpr (kMultiRow) {
 				constexpr int PP = KT / 2, PS = PP | 1, RPI = kWave / PS;   // pieces, stride in pieces, rows per instruction
@@ -258,6 +312,48 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 					if (rr < RPI && piece < PP && n < cnt)
 						__builtin_amdgcn_global_load_lds((mf_gvoid *) src, (mf_lvoid *) (tile + n0 * S), 16, 0, 0);
 				}
+			} else if constexpr (PF > 0 && NP == 1) {
+				// Lean issue (a wave walking a long row alone is bound by its own instruction stream, ~17 instructions per
+				// gathered row in the loop below): every lane forms the address of ITS entry's row once per chunk (one
+				// 64-bit multiply-add per chunk instead of four scalar multiplies per row); per row two v_readlane give the
+				// row base as a scalar pair and the transfer takes it as its scalar address with the lane's 16-byte offset
+				// as the vector part.  The asm opens with s_nop 4: an SGPR written by v_readlane needs five wait states
+				// before a VMEM instruction reads it as its address, and hipcc pads nothing inside an asm statement.
+				const unsigned long long rowaddr = ybase + (unsigned long long) (unsigned) my_idx * (unsigned long long) ybytes;
+				const int alo = (int) (unsigned) rowaddr, ahi = (int) (unsigned) (rowaddr >> 32);
+				const unsigned tile_lds = (unsigned) (unsigned long long) (__attribute__((address_space(3))) char *) tile;
+				int n = 0;
+				for (; n + 4 <= cnt; n += 4) {
+					unsigned long long b[4];
+#pragma unroll
+					for (int u = 0; u < 4; ++u)
+						b[u] = ((unsigned long long) (unsigned) __builtin_amdgcn_readlane(ahi, n + u) << 32) |
+						       (unsigned long long) (unsigned) __builtin_amdgcn_readlane(alo, n + u);
+					if (lane < P) {
+#pragma unroll
+						for (int u = 0; u < 4; ++u)
+							asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0"
+							             :
+							             : "s"(b[u]), "s"(tile_lds + (unsigned) ((n + u) * S)), "v"(voff)
+							             : "memory");
+					}
+				}
+				for (; n < cnt; ++n) {
+					const unsigned long long b = ((unsigned long long) (unsigned) __builtin_amdgcn_readlane(ahi, n) << 32) |
+					                             (unsigned long long) (unsigned) __builtin_amdgcn_readlane(alo, n);
+					if (lane < P)
+						asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0"
+						             :
+						             : "s"(b), "s"(tile_lds + (unsigned) (n * S)), "v"(voff)
+						             : "memory");
+				}
+				// hipcc knows nothing of these transfers: the barrier below would not wait for them
+				MF_STAMP(t_s1);
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef MF_STAMPS
+				st_issue += t_s1 - t_s0;
+				st_wait += __builtin_amdgcn_s_memtime() - t_s1;
+#endif
 			} else
 			for (int n = 0; n < cnt; ++n) {
 				const int j = __builtin_amdgcn_readlane(my_idx, n);
@@ -272,12 +368,15 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 				}
 			}
 			__syncthreads();   // single-wave workgroup: this is the vmcnt(0)/lgkmcnt(0) that retires the DMA
+			MF_STAMP(t_a0);
 			// ---- phase A
 			double e;
 			{
 				const double2 *t2 = reinterpret_cast<const double2 *>(tile + (lane < nch ? lane : 0) * S);   // lanes beyond the tile re-read row 0
 				double dot = 0.0;
-				if (KT > 0) {
+				if constexpr (KT > 0 && PF > 0) {
+					dot = phase_a_dot_pipelined<KT / 2, PF>(t2, xs);
+				} else if (KT > 0) {
 #pragma unroll
 					for (int q = 0; q < KT / 2; ++q) {
 						const double2 t = t2[q];
@@ -309,6 +408,10 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 				}
 				e = a.c2 * (my_val - dot);
 			}
+#ifdef MF_STAMPS
+			asm volatile("" : "+v"(e));
+#endif
+			MF_STAMP(t_a1);
 			if (ERRORS) {
 				if (lane < cnt) {
 					a.err_a[2 * (size_t) (c + lane) + 1] = e;
@@ -343,6 +446,21 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 			// ---- phase B
 			const char *tb = tile + voff;
 			int n = 0;
+			if constexpr (PF > 0 && NP == 1) {   // sixteen entries' reads in flight at once
+				for (; n + 16 <= cnt; n += 16) {
+					double2 t[16];
+#pragma unroll
+					for (int u = 0; u < 16; ++u)
+						t[u] = (lane < P) ? *reinterpret_cast<const double2 *>(tb + (n + u) * S) : make_double2(0.0, 0.0);
+					asm volatile("" ::: "memory");   // pins the issue order: the reads above go out before the arithmetic below
+#pragma unroll
+					for (int u = 0; u < 16; ++u) {
+						const double en = readlane_f64(e, n + u);
+						acc[0].x = acc[0].x + en * t[u].x;
+						acc[0].y = acc[0].y + en * t[u].y;
+					}
+				}
+			}
 			for (; n + 4 <= cnt; n += 4) {
 				double2 t[4][NP];
 				double en[4];
@@ -374,7 +492,23 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 					}
 			}
 			__syncthreads();   // tile is overwritten by the next chunk's DMA
+#ifdef MF_STAMPS
+			st_a += t_a1 - t_a0;
+			st_b += __builtin_amdgcn_s_memtime() - t_a1;
+			++st_chunks;
+#endif
 		}
+#ifdef MF_STAMPS
+		if (end - beg >= 1024 && lane == 0 && PF > 0) {
+			atomicAdd(&mf_stamp_buf[0], 1ull);
+			atomicAdd(&mf_stamp_buf[1], st_chunks);
+			atomicAdd(&mf_stamp_buf[2], st_issue);
+			atomicAdd(&mf_stamp_buf[3], st_wait);
+			atomicAdd(&mf_stamp_buf[4], st_a);
+			atomicAdd(&mf_stamp_buf[5], st_b);
+			atomicAdd(&mf_stamp_buf[6], __builtin_amdgcn_s_memtime() - t_row0);
+		}
+#endif
 		if (!SEGMENTS) {
 			double2 *__restrict__ out2 = reinterpret_cast<double2 *>(a.X_new + (size_t) r * a.ldx);
 #pragma unroll
@@ -383,6 +517,217 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 				if (q < P) out2[q] = acc[p];
 			}
 		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sweep kernel, intra-wave double-buffered form: for launches that cannot fill the chip (a few thousand rows, the
+// cfg3 shapes; the rows left beside the extreme-row path).  sweep_dma_kernel alternates "gather a chunk" and "compute on
+// it" and relies on the OTHER resident workgroups for bytes in flight; with ~15 rows per CU, and one or two long rows
+// left per CU at the end, nothing hides the gather.  Here the wave itself keeps the gather of chunk c+1 in flight under
+// phases A and B of chunk c: two tiles, the LDS-DMA from inline asm (so hipcc does not drain vmcnt in front of every LDS
+// read that might alias a transfer it knows of), one `s_waitcnt vmcnt(0)` per chunk at the top of the loop.  No counted
+// vmcnt is needed: in issue order the queue holds [DMA(c) | idx,val(c+1)] when iteration c starts and everything in it
+// must have arrived before chunk c is computed and chunk c+1 is issued; what stays in flight under the phases is
+// [DMA(c+1) | idx,val(c+2)], which nothing touches before the next vmcnt(0) (hipcc's own waits for idx/val count only its
+// own loads: with foreign transfers behind them they can only wait longer, never too little).
+// Same arithmetic in the same order as sweep_dma_kernel: same bits.  Twice the LDS per workgroup, so only chosen where
+// occupancy is not what hides latency (choose_sweep / launch_sweep: few rows per CU).  Accumulate mode only.
+// ------------------------------------------------------------------------------------------------
+template <int KT, int NPASS>
+__global__ void __launch_bounds__(kWave) sweep_db_kernel(SweepArgs a)
+{
+	const int K = KT > 0 ? KT : a.K;
+	const int P = K >> 1;
+	constexpr int NP = NPASS;
+	const int S = 16 * (P | 1);
+	const int xs_bytes = ((K * 8 + 255) / 256) * 256;
+	extern __shared__ __attribute__((aligned(16))) char lds[];
+	double2 *xs = reinterpret_cast<double2 *>(lds);
+	const int nch = a.nch;
+	const int tile_bytes = nch * S;
+	char *tile0 = lds + xs_bytes;
+	const unsigned tile0_lds = (unsigned) (unsigned long long) (__attribute__((address_space(3))) char *) tile0;
+	const int lane = threadIdx.x;
+	const unsigned voff = (unsigned) lane * 16u;
+	const unsigned long long ybase = (unsigned long long) a.Y_old;
+	const size_t ybytes = (size_t) a.ldy * 8;
+
+	// gather of one chunk into tile `buf`: the rows of lanes 0..cnt-1 of `idx`
+	auto stage = [&](int idx, int cnt, int buf) {
+		const unsigned tb = tile0_lds + (unsigned) (buf * tile_bytes);
+		constexpr bool kMultiRow = KT > 0 && ((KT / 2) | 1) <= 32;
+		if constexpr (kMultiRow) {
+			constexpr int PP = KT / 2, PS = PP | 1, RPI = kWave / PS;
+			const int rr = lane / PS, piece = lane - rr * PS;
+			for (int n0 = 0; n0 < cnt; n0 += RPI) {
+				const int n = n0 + rr;
+				const int j = __shfl(idx, n < cnt ? n : 0);
+				const char *src = reinterpret_cast<const char *>(ybase) + (size_t) (unsigned) j * ybytes + 16 * piece;
+				const unsigned m0 = __builtin_amdgcn_readfirstlane(tb + (unsigned) (n0 * S));
+				if (rr < RPI && piece < PP && n < cnt)
+					asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0) : "memory");
+			}
+		} else
+			for (int n = 0; n < cnt; ++n) {
+				const int j = __builtin_amdgcn_readlane(idx, n);
+				unsigned long long base = ybase + (unsigned long long) (unsigned) j * (unsigned long long) ybytes;
+				asm volatile("" : "+s"(base));
+#pragma unroll
+				for (int p = 0; p < NP; ++p) {
+					const char *src = reinterpret_cast<const char *>(base) + voff + 1024u * p;
+					const unsigned m0 = __builtin_amdgcn_readfirstlane(tb + (unsigned) (n * S + 1024 * p));
+					if (lane + kWave * p < P)
+						asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0) : "memory");
+				}
+			}
+	};
+
+	for (int it = blockIdx.x; it < a.nrows; it += gridDim.x) {
+		const int r = a.rowlist ? a.rowlist[it] : it;
+		const int beg = a.ptr[r], end = a.ptr[r + 1];
+		const double2 *__restrict__ xrow2 = reinterpret_cast<const double2 *>(a.X_old + (size_t) r * a.ldx);
+		double2 acc[NP];
+#pragma unroll
+		for (int p = 0; p < NP; ++p) {
+			const int q = lane + kWave * p;
+			double2 v = make_double2(0.0, 0.0);
+			if (q < P) {
+				v = xrow2[q];
+				xs[q] = v;
+			}
+			acc[p] = a.seed ? v : make_double2(0.0, 0.0);
+		}
+		// chunk c's (idx, val) in cur_*, chunk c+1's in nx_*; the gather of chunk c is issued one iteration ahead
+		int cur_idx = 0, nx_idx = 0;
+		double cur_val = 0.0, nx_val = 0.0;
+		if (beg + lane < min(end, beg + nch)) {
+			cur_idx = a.idx[beg + lane];
+			cur_val = a.val[beg + lane];
+		}
+		if (beg + nch + lane < min(end, beg + 2 * nch)) {
+			nx_idx = a.idx[beg + nch + lane];
+			nx_val = a.val[beg + nch + lane];
+		}
+		// (the asm statements on idx/val below pin hipcc's own vmcnt for these loads HERE, in front of the gather loop:
+		// left alone it re-waits for them inside the loop, behind every transfer it knows nothing of -- one row at a time)
+		asm volatile("" : "+v"(cur_idx));
+		if (beg < end) stage(cur_idx, min(nch, end - beg), 0);
+		int buf = 0;
+		for (int c = beg; c < end; c += nch, buf ^= 1) {
+			const int cnt = min(nch, end - c);
+			const double my_val = cur_val;
+			// everything in flight has arrived: the tile of chunk c, and (idx, val) of chunk c+1
+			asm volatile("s_waitcnt vmcnt(0)" : "+v"(nx_idx), "+v"(nx_val), "+v"(cur_val)::"memory");
+			// the other tile was last read by phase B of chunk c-1 (its reads are complete: their results were consumed)
+			if (c + nch < end) stage(nx_idx, min(nch, end - (c + nch)), buf ^ 1);
+			cur_idx = nx_idx;
+			cur_val = nx_val;
+			nx_idx = 0;
+			nx_val = 0.0;
+			if (c + 2 * nch + lane < min(end, c + 3 * nch)) {
+				nx_idx = a.idx[c + 2 * nch + lane];
+				nx_val = a.val[c + 2 * nch + lane];
+			}
+			const char *tile = tile0 + buf * tile_bytes;
+			// ---- phase A
+			double e;
+			{
+				const double2 *t2 = reinterpret_cast<const double2 *>(tile + (lane < nch ? lane : 0) * S);
+				double dot = 0.0;
+				if constexpr (KT > 0) {
+					dot = phase_a_dot_pipelined<KT / 2, 8>(t2, xs);
+				} else if (KT > 0) {
+#pragma unroll
+					for (int q = 0; q < KT / 2; ++q) {
+						const double2 t = t2[q];
+						const double2 x = xs[q];
+						dot = dot + x.x * t.x;
+						dot = dot + x.y * t.y;
+					}
+				} else {
+					int q = 0;
+					for (; q + 4 <= P; q += 4) {
+						double2 t[4], x[4];
+#pragma unroll
+						for (int u = 0; u < 4; ++u) {
+							t[u] = t2[q + u];
+							x[u] = xs[q + u];
+						}
+#pragma unroll
+						for (int u = 0; u < 4; ++u) {
+							dot = dot + x[u].x * t[u].x;
+							dot = dot + x[u].y * t[u].y;
+						}
+					}
+					for (; q < P; ++q) {
+						const double2 t = t2[q];
+						const double2 x = xs[q];
+						dot = dot + x.x * t.x;
+						dot = dot + x.y * t.y;
+					}
+				}
+				e = a.c2 * (my_val - dot);
+			}
+			// ---- phase B
+			const char *tb = tile + voff;
+			int n = 0;
+			if constexpr (NP == 1) {   // sixteen entries' reads in flight at once
+				for (; n + 16 <= cnt; n += 16) {
+					double2 t[16];
+#pragma unroll
+					for (int u = 0; u < 16; ++u)
+						t[u] = (lane < P) ? *reinterpret_cast<const double2 *>(tb + (n + u) * S) : make_double2(0.0, 0.0);
+					asm volatile("" ::: "memory");   // pins the issue order: the reads above go out before the arithmetic below
+#pragma unroll
+					for (int u = 0; u < 16; ++u) {
+						const double en = readlane_f64(e, n + u);
+						acc[0].x = acc[0].x + en * t[u].x;
+						acc[0].y = acc[0].y + en * t[u].y;
+					}
+				}
+			}
+			for (; n + 4 <= cnt; n += 4) {
+				double2 t[4][NP];
+				double en[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					en[u] = readlane_f64(e, n + u);
+#pragma unroll
+					for (int p = 0; p < NP; ++p)
+						t[u][p] = (lane + kWave * p < P) ? *reinterpret_cast<const double2 *>(tb + (n + u) * S + 1024 * p)
+						                                 : make_double2(0.0, 0.0);
+				}
+#pragma unroll
+				for (int u = 0; u < 4; ++u)
+#pragma unroll
+					for (int p = 0; p < NP; ++p) {
+						acc[p].x = acc[p].x + en[u] * t[u][p].x;
+						acc[p].y = acc[p].y + en[u] * t[u][p].y;
+					}
+			}
+			for (; n < cnt; ++n) {
+				const double en = readlane_f64(e, n);
+#pragma unroll
+				for (int p = 0; p < NP; ++p)
+					if (lane + kWave * p < P) {
+						const double2 t = *reinterpret_cast<const double2 *>(tb + n * S + 1024 * p);
+						acc[p].x = acc[p].x + en * t.x;
+						acc[p].y = acc[p].y + en * t.y;
+					}
+			}
+			// all LDS reads of this tile are complete before a later iteration's transfer may land in it
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		}
+		{
+			double2 *__restrict__ out2 = reinterpret_cast<double2 *>(a.X_new + (size_t) r * a.ldx);
+#pragma unroll
+			for (int p = 0; p < NP; ++p) {
+				const int q = lane + kWave * p;
+				if (q < P) out2[q] = acc[p];
+			}
+		}
+		// xs is rewritten for the next row: its reads (phase A) are complete (lgkmcnt(0) above)
 	}
 }
 
@@ -401,7 +746,20 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 // (gfx90a+ DPP on FP64: row_newbcast only, and only on VOP1/VOP2 encodings -- v_add_f64 is VOP3, v_fmac_f64 is VOP2).
 // The product by 1.0 is exact, so the single rounding is that of the add: the same bits as acc + v.  (The first form had
 // every lane read all 16 entries: 16 ds_read_b128 of 1 KiB per block and wave, 512 LDS cycles per block with four waves
-// on a CU -- 217 ns per block for the longest row of the cfg3 power-law shape against 150 now; tools/micro/osum_probe.)
+// on a CU -- 217 ns per block for the longest row of the cfg3 power-law shape against 150 now; tools/micro/osum_probe.
+// That form is still here as the DPP = false instantiation, selected at plan creation by MF_OS_DPP=0.)
+//
+// Hand-written region, invariants by construction (tests/test_isa.py checks them on the built code object):
+//   * an LDS read whose result hipcc cannot see pending (inline asm) is WAITED FOR INSIDE THE SAME asm STATEMENT, and its
+//     destination is an early-clobber output: no register holds a pending LDS return across statements, so no compiler
+//     copy, spill or reuse can observe one (cdna_hip_programming.md 5.7 item 1, form (i));
+//   * no LDS read is in flight while the v_fmac_f64_dpp chain executes.  Round 2 shipped, for a while, a loop that issued
+//     the read of block b+1 BEFORE the chain of block b and waited for it after: one wrong entry (all four DPP rows,
+//     both columns = one 64-byte piece of scratch) every ~1e8 blocks, only beside another kernel on a busy chip.  The ISA
+//     of that build is clean on paper (tools/micro/alt/libmatfact_hip_base.so: the pending quad v[24:27] and the quad
+//     under the chain v[6:9] are distinct, nothing reads, writes or copies the pending quad before its lgkmcnt(0), every
+//     vmcnt is where the source puts it), so the compiler is not the cause; what the hardware does there is not
+//     established.  The read-then-wait-then-chain order below was clean over 9000 lockstep iterations.
 //
 // Depth classes: a CU's miss bandwidth (~29 GB/s) is shared by its resident waves in proportion to what each keeps in
 // flight, so a wave streaming the longest row must hold more than the waves of the merely long rows beside it, or it
@@ -434,7 +792,9 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 // One (row, slice) task with D-1 blocks in flight.  `src` = this lane's 16 bytes of block 0 (piece lane >> 4 of entry
 // lane & 15), `my` = its 16 bytes of ring slot 0, `seed_ptr` = its two columns of X_old (null: start from zero).
-template <int D>
+// DPP = false: the plain form -- every lane reads the 16 entries of its piece (LDS broadcast reads) and adds them with
+// v_add_f64; same DMA image, same order, same bits.
+template <int D, bool DPP>
 __device__ __forceinline__ void ordered_sum_task(const char *src, unsigned ring_base, unsigned my, int cnt,
                                                  const double *seed_ptr, double &ax, double &ay, double one,
                                                  unsigned long long &t_issued)
@@ -442,40 +802,87 @@ __device__ __forceinline__ void ordered_sum_task(const char *src, unsigned ring_
 	static_assert(D >= 4 && D <= kRing, "depth");
 	constexpr int EB = kBlockEntries;
 	const int nblk = (cnt + EB - 1) / EB;
+	const unsigned piece_base = (my & ~1023u) + ((my & 1023u) >> 8 << 8);   // plain form: piece p of entry e sits at 256 p + 16 e
+	auto slot_of = [&](int b) { return (unsigned) (b & (kRing - 1)) * 1024u; };
 	auto issue = [&](int b) {
 		const char *g = src + (size_t) b * 1024;
-		const unsigned m0 = __builtin_amdgcn_readfirstlane(ring_base + (unsigned) (b & (kRing - 1)) * 1024u);
+		const unsigned m0 = __builtin_amdgcn_readfirstlane(ring_base + slot_of(b));
 		asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0) : "memory");   // m0 is a reserved register: hipcc re-loads it before each of its own uses
 	};
-	// asm, so that it stays where it is written (hipcc sinks an ordinary LDS read next to its first use)
-	auto read_block = [&](int b, v2d &v) {
-		const unsigned addr = my + (unsigned) (b & (kRing - 1)) * 1024u;
-		asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+	// Block b out of the ring into registers, complete when the statement ends (early-clobber output, the wait inside).
+	// ISSUE: the DMA of block `nb` goes out between the read and its wait, so a part of the read's latency is hidden.
+	// WAIT = how many newer DMAs may still be outstanding for block b to have landed (-1: the caller has waited).
+	auto fetch = [&](int b, v2d &v, auto wait_tag, int nb) {
+		constexpr int WAIT = decltype(wait_tag)::value;
+		const unsigned addr = my + slot_of(b);
+		if constexpr (WAIT >= 0) {   // steady state: nb = b + D - 1 is always a block of the row
+			const char *g = src + (size_t) nb * 1024;
+			const unsigned m0 = __builtin_amdgcn_readfirstlane(ring_base + slot_of(nb));
+			asm volatile("s_waitcnt vmcnt(%4)\n\t"
+			             "ds_read_b128 %0, %1\n\t"
+			             "s_mov_b32 m0, %3\n\t"
+			             "s_nop 0\n\t"
+			             "global_load_lds_dwordx4 %2, off\n\t"
+			             "s_waitcnt lgkmcnt(0)"
+			             : "=&v"(v)
+			             : "v"(addr), "v"(g), "s"(m0), "n"(WAIT)
+			             : "memory");
+		} else {
+			(void) nb;
+			asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+		}
 	};
-	auto landed = [&](v2d &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)::"memory"); };
-	auto add16 = [&](const v2d &v) {
-		MF_FMAC_BCAST(0); MF_FMAC_BCAST(1); MF_FMAC_BCAST(2); MF_FMAC_BCAST(3);
-		MF_FMAC_BCAST(4); MF_FMAC_BCAST(5); MF_FMAC_BCAST(6); MF_FMAC_BCAST(7);
-		MF_FMAC_BCAST(8); MF_FMAC_BCAST(9); MF_FMAC_BCAST(10); MF_FMAC_BCAST(11);
-		MF_FMAC_BCAST(12); MF_FMAC_BCAST(13); MF_FMAC_BCAST(14); MF_FMAC_BCAST(15);
-	};
-	auto add_some = [&](const v2d &v, int n) {   // the last, partial block of a row
-		if (n > 0) MF_FMAC_BCAST(0);
-		if (n > 1) MF_FMAC_BCAST(1);
-		if (n > 2) MF_FMAC_BCAST(2);
-		if (n > 3) MF_FMAC_BCAST(3);
-		if (n > 4) MF_FMAC_BCAST(4);
-		if (n > 5) MF_FMAC_BCAST(5);
-		if (n > 6) MF_FMAC_BCAST(6);
-		if (n > 7) MF_FMAC_BCAST(7);
-		if (n > 8) MF_FMAC_BCAST(8);
-		if (n > 9) MF_FMAC_BCAST(9);
-		if (n > 10) MF_FMAC_BCAST(10);
-		if (n > 11) MF_FMAC_BCAST(11);
-		if (n > 12) MF_FMAC_BCAST(12);
-		if (n > 13) MF_FMAC_BCAST(13);
-		if (n > 14) MF_FMAC_BCAST(14);
-		if (n > 15) MF_FMAC_BCAST(15);
+	auto add_block = [&](int b, int n, auto wait_tag, int nb) {   // entries 0..n-1 of block b onto (ax, ay), in order
+		if constexpr (DPP) {
+			v2d v;
+			fetch(b, v, wait_tag, nb);
+			if (n == EB) {
+				MF_FMAC_BCAST(0); MF_FMAC_BCAST(1); MF_FMAC_BCAST(2); MF_FMAC_BCAST(3);
+				MF_FMAC_BCAST(4); MF_FMAC_BCAST(5); MF_FMAC_BCAST(6); MF_FMAC_BCAST(7);
+				MF_FMAC_BCAST(8); MF_FMAC_BCAST(9); MF_FMAC_BCAST(10); MF_FMAC_BCAST(11);
+				MF_FMAC_BCAST(12); MF_FMAC_BCAST(13); MF_FMAC_BCAST(14); MF_FMAC_BCAST(15);
+			} else {   // the last, partial block of a row
+				if (n > 0) MF_FMAC_BCAST(0);
+				if (n > 1) MF_FMAC_BCAST(1);
+				if (n > 2) MF_FMAC_BCAST(2);
+				if (n > 3) MF_FMAC_BCAST(3);
+				if (n > 4) MF_FMAC_BCAST(4);
+				if (n > 5) MF_FMAC_BCAST(5);
+				if (n > 6) MF_FMAC_BCAST(6);
+				if (n > 7) MF_FMAC_BCAST(7);
+				if (n > 8) MF_FMAC_BCAST(8);
+				if (n > 9) MF_FMAC_BCAST(9);
+				if (n > 10) MF_FMAC_BCAST(10);
+				if (n > 11) MF_FMAC_BCAST(11);
+				if (n > 12) MF_FMAC_BCAST(12);
+				if (n > 13) MF_FMAC_BCAST(13);
+				if (n > 14) MF_FMAC_BCAST(14);
+			}
+		} else {
+			constexpr int WAIT = decltype(wait_tag)::value;
+			if constexpr (WAIT >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT) : "memory");
+			const unsigned addr = piece_base + slot_of(b);
+			v2d w[EB];
+			// 16 reads and their wait in one statement (the ring is written by LDS-DMA hipcc knows nothing of)
+			asm volatile("ds_read_b128 %0, %16\n\tds_read_b128 %1, %16 offset:16\n\tds_read_b128 %2, %16 offset:32\n\t"
+			             "ds_read_b128 %3, %16 offset:48\n\tds_read_b128 %4, %16 offset:64\n\tds_read_b128 %5, %16 offset:80\n\t"
+			             "ds_read_b128 %6, %16 offset:96\n\tds_read_b128 %7, %16 offset:112\n\tds_read_b128 %8, %16 offset:128\n\t"
+			             "ds_read_b128 %9, %16 offset:144\n\tds_read_b128 %10, %16 offset:160\n\tds_read_b128 %11, %16 offset:176\n\t"
+			             "ds_read_b128 %12, %16 offset:192\n\tds_read_b128 %13, %16 offset:208\n\tds_read_b128 %14, %16 offset:224\n\t"
+			             "ds_read_b128 %15, %16 offset:240\n\ts_waitcnt lgkmcnt(0)"
+			             : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7]),
+			               "=&v"(w[8]), "=&v"(w[9]), "=&v"(w[10]), "=&v"(w[11]), "=&v"(w[12]), "=&v"(w[13]), "=&v"(w[14]),
+			               "=&v"(w[15])
+			             : "v"(addr)
+			             : "memory");
+			if (nb >= 0) issue(nb);
+#pragma unroll
+			for (int e = 0; e < EB; ++e)
+				if (e < n) {
+					ax = ax + w[e].x;
+					ay = ay + w[e].y;
+				}
+		}
 	};
 	// Hand-counted region.  The seed travels like a block -- an LDS-DMA transfer into a slot of its own, issued BEFORE
 	// the blocks: LDS-DMA transfers land in order, so it has landed whenever block 0 has, and its round trip runs beside
@@ -486,11 +893,11 @@ __device__ __forceinline__ void ordered_sum_task(const char *src, unsigned ring_
 		const unsigned m0 = __builtin_amdgcn_readfirstlane(ring_base + (unsigned) kRing * 1024u);
 		asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(seed_ptr), "s"(m0) : "memory");
 	}
-	auto read_seed = [&]() {
+	auto read_seed = [&]() {   // caller: the seed's transfer has landed
 		v2d sv = {0.0, 0.0};
 		if (seed_ptr) {
 			const unsigned addr = my + (unsigned) kRing * 1024u;
-			asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(sv) : "v"(addr) : "memory");
+			asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(sv) : "v"(addr) : "memory");
 		}
 		ax = sv.x;
 		ay = sv.y;
@@ -499,58 +906,21 @@ __device__ __forceinline__ void ordered_sum_task(const char *src, unsigned ring_
 	for (int b = 0; b < ahead; ++b) issue(b);
 	t_issued = __builtin_amdgcn_s_memrealtime();   // (probe) no store inside the hand-counted region
 	int b = 0;
-	// Steady state: the 16 dependent adds of block b (the true critical path), then the read of block b+1.
-	// D-1 blocks are issued beyond b-1, so block b+1 has landed once at most D-3 newer DMAs are outstanding; the slot
-	// refilled after the adds of block b is free: its last reader was block b+D-1-kRing <= b-1, read two steps ago.
+	// Steady state, per block b: wait until b has landed -- blocks up to b+D-2 are issued, so at most the D-2 newer ones
+	// may be outstanding --, read it, issue block b+D-1 into the slot of block b-1 (read and added one step ago; with
+	// D-1 < kRing an older one), then the 16 dependent adds, the true critical path.
 	if (nblk > D - 1) {   // at least one block is still to be issued
-		v2d cur, nxt;
-		asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 2) : "memory");
+		asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 2) : "memory");   // block 0, and the seed in front of it
 		read_seed();
-		read_block(0, cur);
-		// The LDS read of the next block is issued AFTER the adds, never before them: an LDS read returning into
-		// registers while the v_fmac_f64_dpp chain executes was seen to corrupt the chain -- one entry of one block
-		// (all four DPP rows, both columns) every ~1e8 blocks, only beside the sweep of the remaining rows on a busy
-		// chip (tools/skew_dbg.py on the tenth-scale Netflix shape with MF_SWEEP_LONG=3000: 4 bad iterations per ~150;
-		// with the read after the adds, or without DPP, none in 1200).  The read's latency is then exposed at the top
-		// of the next step; the DMA issue in between hides a part of it, the iteration loses 0.5 %.
-		auto step = [&](int blk, v2d &have, v2d &want) {
-			landed(have);
-			add16(have);
-			asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 3) : "memory");
-			read_block(blk + 1, want);
-			issue(blk + D - 1);
-		};
-		for (; b + D < nblk; b += 2) {   // two blocks per trip: the two registers swap roles, no copies
-			step(b, cur, nxt);
-			step(b + 1, nxt, cur);
-		}
-		if (b + (D - 1) < nblk) {
-			step(b, cur, nxt);
-			cur = nxt;
-			++b;
-		}
-		// `cur` holds block b (a full one: b + D - 1 == nblk here), not yet added
-		landed(cur);
-		add16(cur);
-		++b;
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	} else {
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		read_seed();
+		for (; b + (D - 1) < nblk; ++b) add_block(b, EB, std::integral_constant<int, D - 2>{}, b + D - 1);
 	}
-	for (; b < nblk; ++b) {
-		v2d v;
-		read_block(b, v);
-		landed(v);
-		const int n = min(EB, cnt - EB * b);
-		if (n == EB)
-			add16(v);
-		else
-			add_some(v, n);
-	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	if (b == 0) read_seed();
+	for (; b < nblk; ++b) add_block(b, min(EB, cnt - EB * b), std::integral_constant<int, -1>{}, -1);
 }
 #undef MF_FMAC_BCAST
 
+template <bool DPP>
 __global__ void __launch_bounds__(kWave) ordered_sum_kernel(OrderedSumArgs a)
 {
 	static_assert(kSliceCols == 8, "row p of the wave = piece p of the slice: four pieces");
@@ -579,11 +949,11 @@ __global__ void __launch_bounds__(kWave) ordered_sum_kernel(OrderedSumArgs a)
 		double ax = 0.0, ay = 0.0;
 		// in flight: all of the ring for the longest rows, a half or a quarter of it for the shorter ones
 		if (4 * (long long) cnt >= 2 * (long long) a.max_cnt)
-			ordered_sum_task<kRing>(src, ring_base, my, cnt, seed_ptr, ax, ay, one, t_issued);
+			ordered_sum_task<kRing, DPP>(src, ring_base, my, cnt, seed_ptr, ax, ay, one, t_issued);
 		else if (4 * (long long) cnt >= (long long) a.max_cnt)
-			ordered_sum_task<kRing / 2>(src, ring_base, my, cnt, seed_ptr, ax, ay, one, t_issued);
+			ordered_sum_task<kRing / 2, DPP>(src, ring_base, my, cnt, seed_ptr, ax, ay, one, t_issued);
 		else
-			ordered_sum_task<kRing / 4>(src, ring_base, my, cnt, seed_ptr, ax, ay, one, t_issued);
+			ordered_sum_task<kRing / 4, DPP>(src, ring_base, my, cnt, seed_ptr, ax, ay, one, t_issued);
 		if (live && ent == 0) *reinterpret_cast<double2 *>(a.X_new + (size_t) r * a.ldx + k0) = make_double2(ax, ay);
 		if (stamp) {
 			stamp[0] = t_start;

@@ -7,6 +7,7 @@
 
 #include <errno.h>
 #include <fcntl.h>
+#include <pthread.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -278,24 +279,31 @@ int mf_host_parse_file(const char *path, mf_problem *p)
 /* ---- binary cache of parsed `.in` files: the per-token fscanf of util.c:30-34 is the wall-clock floor
  * of a repeat run once the iterations are on the GPU.  A cache file holds the header and the entries exactly as the
  * parser produced them (the reference's own 16-byte non_zero_entry structs) under a key made of the CONTENT of the
- * `.in` (64-bit FNV-1a over 1-MiB blocks, hashed in parallel) and its size, so an edited file can never be served
- * from a stale cache.  A hit maps the cache file and points mf_problem.entries into the mapping (no copy, no
- * parse); anything unexpected -- no directory, short file, other magic, other key -- falls back to the parser. */
-typedef struct mf_cache_header {
-	char magic[8];              /* "MFCACHE1" */
-	uint64_t content_hash;
+ * `.in` (64-bit FNV-1a over 1-MiB blocks, hashed in parallel) and its size: an edited file misses unless its text
+ * collides in 64 bits at equal length (not a cryptographic guarantee).  A hit maps the cache file, checks the hash of
+ * the stored entries against the header (a damaged body is a miss) and points mf_problem.entries into the mapping (no
+ * copy, no parse); anything unexpected -- no directory, short file, other magic, other key, other body hash -- falls
+ * back to the parser.  The entries are served as parsed: like the reference's parser (util.c:30-34) this layer does not
+ * range-check indices; mf_plan_create / mf_backend_run* do, and answer MF_ERR_ARGUMENT. */
+typedef struct {
+	char magic[8];              /* "MFCACHE2" */
+	uint64_t content_hash;      /* of the .in text */
 	uint64_t content_size;
 	int32_t users, items, features, iters;
 	double alpha;
 	int64_t nnz;
-	char pad[8];                /* entries start at byte 64 */
-} mf_cache_header;
+	uint64_t body_hash;         /* of the entries as stored: a damaged cache body is a miss, not a wrong answer */
+} mf_cache_header;              /* 64 bytes: entries start at byte 64 */
 
-#define MF_MAX_MAPPINGS 16
-static struct {
+/* live mappings of cache files (mf_problem.entries points 64 bytes into one): a list under a mutex, so any number of
+ * problems may be open and concurrent callers do not race */
+typedef struct mf_mapping {
 	void *base;
 	size_t size;
-} g_mappings[MF_MAX_MAPPINGS];
+	struct mf_mapping *next;
+} mf_mapping;
+static mf_mapping *g_mappings;
+static pthread_mutex_t g_mappings_mu = PTHREAD_MUTEX_INITIALIZER;
 
 static uint64_t fnv1a64(const unsigned char *p, size_t n)
 {
@@ -348,29 +356,34 @@ int mf_host_parse_file_cached(const char *path, const char *cache_dir, mf_proble
 	if (cfd >= 0) {
 		struct stat cst;
 		mf_cache_header h;
-		int slot = -1;
-		for (int i = 0; i < MF_MAX_MAPPINGS; ++i)
-			if (!g_mappings[i].base) slot = i;
-		if (slot >= 0 && fstat(cfd, &cst) == 0 && (size_t) cst.st_size >= sizeof h &&
-		    pread(cfd, &h, sizeof h, 0) == (ssize_t) sizeof h && memcmp(h.magic, "MFCACHE1", 8) == 0 &&
+		if (fstat(cfd, &cst) == 0 && (size_t) cst.st_size >= sizeof h &&
+		    pread(cfd, &h, sizeof h, 0) == (ssize_t) sizeof h && memcmp(h.magic, "MFCACHE2", 8) == 0 &&
 		    h.content_hash == key && h.content_size == (uint64_t) len && h.nnz >= 0 && h.users >= 0 && h.items >= 0 &&
 		    (uint64_t) cst.st_size == sizeof h + (uint64_t) h.nnz * sizeof(mf_entry)) {
 			void *map = mmap(NULL, (size_t) cst.st_size, PROT_READ, MAP_PRIVATE, cfd, 0);
-			if (map != MAP_FAILED) {
-				g_mappings[slot].base = map;
-				g_mappings[slot].size = (size_t) cst.st_size;
+			mf_mapping *node = map != MAP_FAILED ? malloc(sizeof *node) : NULL;
+			/* the body is trusted only as far as its own hash: what was parsed is what is served */
+			if (node && content_hash((const unsigned char *) map + sizeof h, (size_t) h.nnz * sizeof(mf_entry)) == h.body_hash) {
+				node->base = map;
+				node->size = (size_t) cst.st_size;
+				pthread_mutex_lock(&g_mappings_mu);
+				node->next = g_mappings;
+				g_mappings = node;
+				pthread_mutex_unlock(&g_mappings_mu);
 				p->users = h.users;
 				p->items = h.items;
 				p->features = h.features;
 				p->iters = h.iters;
 				p->alpha = h.alpha;
 				p->nnz = h.nnz;
-				p->entries = (const mf_entry *) ((const char *) map + sizeof h);
+				p->entries = (const mf_entry *) ((const char *) map + sizeof h);   /* nnz == 0: one past the header, never read */
 				close(cfd);
 				munmap(text, len);
 				if (cache_hit) *cache_hit = 1;
 				return MF_PARSE_OK;
 			}
+			free(node);
+			if (map != MAP_FAILED) munmap(map, (size_t) cst.st_size);
 		}
 		close(cfd);
 	}
@@ -393,7 +406,7 @@ int mf_host_parse_file_cached(const char *path, const char *cache_dir, mf_proble
 	if (out) {
 		mf_cache_header h;
 		memset(&h, 0, sizeof h);
-		memcpy(h.magic, "MFCACHE1", 8);
+		memcpy(h.magic, "MFCACHE2", 8);
 		h.content_hash = key;
 		h.content_size = (uint64_t) len;
 		h.users = p->users;
@@ -403,6 +416,7 @@ int mf_host_parse_file_cached(const char *path, const char *cache_dir, mf_proble
 		h.alpha = p->alpha;
 		h.nnz = p->nnz;
 		const size_t n = (size_t) p->nnz;
+		h.body_hash = content_hash((const unsigned char *) p->entries, n * sizeof(mf_entry));
 		const int ok = fwrite(&h, sizeof h, 1, out) == 1 && (n == 0 || fwrite(p->entries, sizeof(mf_entry), n, out) == n);
 		if (fclose(out) == 0 && ok)
 			(void) rename(tmp, name);   /* atomic: a reader sees the old state or the whole file */
@@ -415,15 +429,24 @@ int mf_host_parse_file_cached(const char *path, const char *cache_dir, mf_proble
 void mf_host_free_problem(mf_problem *p)
 {
 	if (!p) return;
-	int mapped = 0;
-	for (int i = 0; i < MF_MAX_MAPPINGS && p->entries; ++i)
-		if (g_mappings[i].base && (const char *) p->entries >= (const char *) g_mappings[i].base &&
-		    (const char *) p->entries < (const char *) g_mappings[i].base + g_mappings[i].size) {
-			munmap(g_mappings[i].base, g_mappings[i].size);
-			g_mappings[i].base = NULL;
-			mapped = 1;
-		}
-	if (!mapped) free((void *) p->entries);
+	/* a cached problem points sizeof(header) bytes into its mapping -- also when it has no entries at all */
+	mf_mapping *hit = NULL;
+	if (p->entries) {
+		const char *want = (const char *) p->entries - sizeof(mf_cache_header);
+		pthread_mutex_lock(&g_mappings_mu);
+		for (mf_mapping **q = &g_mappings; *q; q = &(*q)->next)
+			if ((const char *) (*q)->base == want) {
+				hit = *q;
+				*q = hit->next;
+				break;
+			}
+		pthread_mutex_unlock(&g_mappings_mu);
+	}
+	if (hit) {
+		munmap(hit->base, hit->size);
+		free(hit);
+	} else
+		free((void *) p->entries);
 	p->entries = NULL;
 	p->nnz = 0;
 }

@@ -26,7 +26,7 @@ def test_libraries_export_every_declared_symbol(capi):
     declared = set(re.findall(r"\b(mf_host_[a-z0-9_]+)\s*\(", hdr)) - {
         "mf_host_block_low", "mf_host_block_high", "mf_host_block_size", "mf_host_block_owner"}
     assert declared == set(capi.HOST_SYMBOLS)
-    assert capi.hip().mf_backend_abi_version() == 4
+    assert capi.hip().mf_backend_abi_version() == 5
 
 
 def test_no_gpu_means_loud_failure_not_fallback(capi):
@@ -301,3 +301,44 @@ def test_binary_cache_of_parsed_inputs(capi, tmp_path):
     # no directory: the plain parser, no failure
     inst, hit = capi.parse_file_cached(str(src), str(tmp_path / "nowhere"))
     assert not hit and np.array_equal(inst.val, plain.val)
+    # one flipped byte in the BODY (the size still fits the header): the stored hash of the entries catches it
+    with open(victim, "r+b") as f:
+        f.seek(64 + 16 * 5 + 8)
+        b = f.read(1)
+        f.seek(64 + 16 * 5 + 8)
+        f.write(bytes([b[0] ^ 0x10]))
+    again, hit5 = capi.parse_file_cached(str(src), str(cache))
+    assert not hit5 and np.array_equal(again.val, plain.val) and np.array_equal(again.col, plain.col)
+    assert capi.parse_file_cached(str(src), str(cache))[1]
+
+
+def test_binary_cache_header_only_instance_and_many_open_problems(capi, tmp_path):
+    """A header-only instance (nnz == 0) is cached as a bare 64-byte header; the hit points one past the mapping's end and
+    must be released as a mapping, not handed to free() (round-2 advisor finding: `free(): invalid pointer`).  More
+    cached problems may be open at once than the 16 slots the first version had."""
+    import ctypes as C
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    empty = tmp_path / "empty.in"
+    empty.write_text("1 0.1 2\n2 2 0\n")
+    for expect_hit in (False, True, True):
+        inst, hit = capi.parse_file_cached(str(empty), str(cache))   # parses, splits and frees the problem
+        assert hit == expect_hit and (inst.users, inst.items, len(inst.row)) == (2, 2, 0)
+    h = capi.host()
+    live = []
+    for n in range(40):
+        f = tmp_path / ("m%d.in" % n)
+        f.write_text("1 0.1 2\n3 3 2\n0 %d 1.0\n2 1 %d.5\n" % (n % 3, n))
+        for _ in range(2):   # miss (writes the cache), then hit (kept open)
+            p = capi.Problem()
+            hit = C.c_int(0)
+            assert h.mf_host_parse_file_cached(os.fsencode(str(f)), os.fsencode(str(cache)), C.byref(p), C.byref(hit)) == 0
+            if hit.value:
+                live.append(p)
+            else:
+                h.mf_host_free_problem(C.byref(p))
+    assert len(live) == 40
+    for n, p in enumerate(live):
+        assert p.nnz == 2 and p.entries[1].value == n + 0.5
+        h.mf_host_free_problem(C.byref(p))
+        assert not p.entries

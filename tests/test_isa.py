@@ -1,0 +1,196 @@
+"""ISA-level invariants of the built gfx950 code object, checked on the CPU by disassembling libmatfact_hip.so
+(llvm-objdump / llvm-readelf of the ROCm image; tools/isa.py).  Bit-exactness against matFact.c rests on structural
+facts of the machine code that no numerical test can see until they break rarely:
+
+  * no fused multiply-add where the reference multiplies and adds separately (matFact.c:45-51, mat2d.c:133-137);
+  * nothing spilled to scratch in the kernels on the timed path;
+  * the matrix-core recommendation really is on v_mfma_f64_16x16x4_f64;
+  * the hand-written regions keep their invariants BY CONSTRUCTION: an LDS read hipcc cannot see (inline asm) is waited
+    for before anything touches its destination, no LDS read is pending while the v_fmac_f64_dpp chain of the ordered
+    sums executes (the order that produced one wrong entry per ~1e8 blocks in round 2), and M0 is written
+    right in front of every LDS-DMA instruction that reads it.
+"""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import isa  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not isa.have_tools() or not os.path.exists(isa.DEFAULT_LIB),
+                                reason="needs llvm-objdump/llvm-readelf/c++filt and the built library")
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    k = {n: b for n, b in isa.disassemble().items() if "rocprim" not in n}
+    assert len(k) > 60, "kernel symbols not found in the code object"
+    return k
+
+
+@pytest.fixture(scope="module")
+def meta():
+    return {n: m for n, m in isa.metadata().items() if "rocprim" not in n}
+
+
+def _ops(body):
+    return [isa.split(i)[0] for i in body]
+
+
+# kernels whose sums must be formed exactly as the serial program forms them: separate multiply and add
+EXACT = ("sweep_kernel", "sweep_dma_kernel", "sweep_coop_kernel", "sweep_resident_kernel", "stream_resident_kernel",
+         "recommend_kernel", "predict_kernel")
+
+
+def test_no_fused_multiply_add_in_the_exact_kernels(kernels):
+    checked = 0
+    for name, body in kernels.items():
+        if not any("mf::" + e in name for e in EXACT):
+            continue
+        checked += 1
+        fused = [i for i in body if re.match(r"v_(fma|fmac|mad|pk_fma)_f64", i)]
+        assert not fused, (name, fused[:3])
+        ops = set(_ops(body))
+        assert "v_mul_f64" in ops and "v_add_f64" in ops, name
+    assert checked >= 60
+
+
+def test_ordered_sums_fuse_only_the_exact_product_by_one(kernels):
+    """v_fmac_f64_dpp acc, v, 1.0: the only FP64 DPP form gfx950 has; the product by 1.0 is exact, the rounding is the
+    add's.  Every one of them must take the SAME register pair as its multiplier (the 1.0), and nothing else fuses."""
+    dpp = kernels["void mf::ordered_sum_kernel<true>(mf::OrderedSumArgs)"]
+    plain = kernels["void mf::ordered_sum_kernel<false>(mf::OrderedSumArgs)"]
+    fm = [i for i in dpp if i.startswith("v_fmac_f64_dpp")]
+    assert len(fm) >= 3 * 2 * 31, len(fm)   # three depth classes x (full block + partial block) of 16 / 15 entries x 2 columns
+    ones = {isa.split(i)[1].split(",")[2].split()[0] for i in fm}
+    assert len(ones) == 1, ones
+    one_regs = isa.regs(next(iter(ones)))
+    for i in dpp:   # the 1.0 is never written after its initialisation inside the loop nest: only v_mov of the constant
+        op, rest = isa.split(i)
+        if op.startswith("v_") and isa.regs(rest.split(",")[0]) & one_regs and not op.startswith("v_fmac_f64_dpp"):
+            assert op in ("v_mov_b32_e32", "v_mov_b64_e32"), i
+    assert all("row_newbcast:" in i and "row_mask:0xf" in i and "bank_mask:0xf" in i for i in fm)
+    assert not [i for i in dpp if re.match(r"v_(fma|fmac)_f64", i) and "_dpp" not in i]
+    assert not [i for i in plain if re.match(r"v_(fma|fmac)_f64", i)]
+    assert "v_add_f64" in _ops(plain)
+
+
+def _walk_pending_lds_reads(body, name):
+    """every inline-asm style LDS read (ds_read_b128) is followed, in straight-line code, by s_waitcnt lgkmcnt(0) before any
+    instruction names a register of its destination; returns the number of reads checked"""
+    n = 0
+    for pos, ins in enumerate(body):
+        op, rest = isa.split(ins)
+        if op != "ds_read_b128":
+            continue
+        dest = isa.regs(rest.split(",")[0])
+        assert len(dest) == 4, ins
+        for nxt in body[pos + 1:]:
+            nop, nrest = isa.split(nxt)
+            if nop == "s_waitcnt" and "lgkmcnt(0)" in nrest:
+                break
+            assert not nop.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")), (name, ins, "control flow before the wait", nxt)
+            assert not (isa.regs(nrest) & dest), (name, ins, "destination touched before lgkmcnt(0)", nxt)
+        else:
+            raise AssertionError((name, ins, "no lgkmcnt(0) after the read"))
+        n += 1
+    return n
+
+
+def test_ordered_sum_lds_reads_are_waited_for_before_their_destination_is_touched(kernels):
+    for form in ("true", "false"):
+        name = "void mf::ordered_sum_kernel<%s>(mf::OrderedSumArgs)" % form
+        assert _walk_pending_lds_reads(kernels[name], name) >= 9   # 3 depth classes x (seed, steady state, tail)
+
+
+def test_no_lds_read_is_pending_under_the_dpp_chain(kernels):
+    """Between a ds_read and its lgkmcnt(0) no v_fmac_f64_dpp may issue, and no ds_read sits inside a chain: the read of
+    block b is complete before the first add of block b, the read of block b+1 starts after the last one."""
+    body = kernels["void mf::ordered_sum_kernel<true>(mf::OrderedSumArgs)"]
+    pending = False
+    chains = 0
+    prev_dpp = False
+    for ins in body:
+        op, rest = isa.split(ins)
+        if op.startswith("ds_read"):
+            pending = True
+        elif op == "s_waitcnt" and "lgkmcnt(0)" in rest:
+            pending = False
+        is_dpp = op == "v_fmac_f64_dpp"
+        if is_dpp:
+            assert not pending, "v_fmac_f64_dpp issued while an LDS read is outstanding"
+            if not prev_dpp and "row_newbcast:0 " in ins + " ":
+                chains += 1
+        prev_dpp = is_dpp
+    assert chains >= 6
+
+
+def test_m0_is_written_in_front_of_every_lds_dma_of_the_ordered_sums(kernels):
+    """M0 (the LDS destination of global_load_lds) is a reserved register hipcc rewrites at will: the asm statement that
+    issues the transfer writes it itself -- s_mov_b32 m0, sX; s_nop 0; global_load_lds_dwordx4."""
+    for form in ("true", "false"):
+        body = kernels["void mf::ordered_sum_kernel<%s>(mf::OrderedSumArgs)" % form]
+        n = 0
+        for pos, ins in enumerate(body):
+            if ins.startswith("global_load_lds_dwordx4"):
+                assert body[pos - 1].startswith("s_nop"), body[pos - 3:pos + 1]
+                assert body[pos - 2].startswith("s_mov_b32 m0,"), body[pos - 3:pos + 1]
+                n += 1
+        assert n >= 6
+
+
+def test_hand_counted_vmcnt_of_the_ordered_sums(kernels):
+    """The steady state of depth class D waits vmcnt(D-2) in front of the read of the block it is about to add: D-1 blocks
+    are issued ahead, so with at most D-2 newer transfers outstanding the block has landed (32 / 16 / 8 -> 30 / 14 / 6)."""
+    body = kernels["void mf::ordered_sum_kernel<true>(mf::OrderedSumArgs)"]
+    seen = set()
+    for pos, ins in enumerate(body):
+        if ins.startswith("ds_read_b128") and body[pos - 1].startswith("s_waitcnt vmcnt("):
+            depth = int(re.search(r"vmcnt\((\d+)\)", body[pos - 1]).group(1))
+            if body[pos + 3].startswith("global_load_lds_dwordx4"):
+                seen.add(depth)
+    assert seen == {30, 14, 6}, seen
+
+
+def test_timed_path_kernels_do_not_spill(kernels, meta):
+    # generic fallbacks that may touch scratch: the odd-K matrix-core form staged through registers
+    allowed = {"void mf::recommend_mfma_kernel<false, 32, false, false>(mf::RecMfmaArgs)"}
+    for name, body in kernels.items():
+        if "mf::" not in name or name in allowed:
+            continue
+        assert not [i for i in body if i.startswith("scratch_")], name
+        m = meta[name]
+        assert m[".private_segment_fixed_size"] == 0 and m[".vgpr_spill_count"] == 0, (name, m)
+    for name in allowed:
+        assert meta[name][".private_segment_fixed_size"] <= 64, meta[name]
+
+
+def test_recommendation_runs_on_the_fp64_matrix_cores(kernels):
+    forms = [n for n in kernels if "recommend_mfma_kernel" in n]
+    assert len(forms) >= 6
+    for n in forms:
+        mf = [i for i in kernels[n] if i.startswith("v_mfma_f64_16x16x4")]
+        assert len(mf) >= 48, (n, len(mf))
+    assert not [i for i in kernels["mf::recommend_kernel(mf::RecArgs)"] if i.startswith("v_mfma")]
+
+
+def test_sweeps_gather_by_lds_dma(kernels):
+    """every LDS-DMA form of the sweep moves its rows with global_load_lds_dwordx4 (no VGPR staging, no ds_write of the tile)"""
+    n = 0
+    for name, body in kernels.items():
+        if "mf::sweep_dma_kernel" in name or "mf::sweep_coop_kernel" in name:
+            assert any(i.startswith("global_load_lds_dwordx4") for i in body), name
+            n += 1
+    assert n >= 30
+
+
+def test_occupancy_budget_of_the_single_wave_kernels(meta):
+    """one-wave workgroups rely on many resident workgroups per CU: the production sweeps stay within 128 VGPRs (4 waves per
+    SIMD by registers; LDS is the tighter bound) and the ordered sums within 64"""
+    for name, m in meta.items():
+        if re.search(r"mf::sweep_dma_kernel<(100|128|256), \d, 0>", name):
+            assert m[".vgpr_count"] <= 128, (name, m[".vgpr_count"])
+    assert meta["void mf::ordered_sum_kernel<true>(mf::OrderedSumArgs)"][".vgpr_count"] <= 64

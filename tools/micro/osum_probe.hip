@@ -19,6 +19,9 @@
 		}                                                                          \
 	} while (0)
 
+// OSUM_PLAIN=1: the plain-add form (MF_OS_DPP=0 in the library) instead of the DPP broadcast form
+static void (*const osum)(mf::OrderedSumArgs) = getenv("OSUM_PLAIN") ? mf::ordered_sum_kernel<false> : mf::ordered_sum_kernel<true>;
+
 // a stand-in for the sweep running beside the ordered sums: single-wave workgroups with a large LDS tile, read 16 bytes
 // per lane over and over (phase A / B of sweep_dma_kernel), plus some global traffic
 __global__ void __launch_bounds__(64) hammer(double *dst, const double *src, size_t n, int rounds)
@@ -103,13 +106,13 @@ int main(int argc, char **argv)
 	CK(hipEventCreate(&b));
 	const size_t lds_list[] = {mf::kOrderedSumLds, 40000, 53000, 80000, 160000};
 	for (size_t lds : lds_list) {
-		CK(hipFuncSetAttribute((const void *) mf::ordered_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+		CK(hipFuncSetAttribute((const void *) osum, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
 		float best = 1e9f, sum = 0.f;
 		const int reps = 10;
 		for (int r = 0; r < reps + 2; ++r) {
 			CK(hipMemsetAsync(flush, r, fbytes, 0));
 			CK(hipEventRecord(a, 0));
-			mf::ordered_sum_kernel<<<nrows * nsl, mf::kWave, lds, 0>>>(o);
+			osum<<<nrows * nsl, mf::kWave, lds, 0>>>(o);
 			CK(hipEventRecord(b, 0));
 			CK(hipEventSynchronize(b));
 			float ms;
@@ -148,12 +151,12 @@ int main(int argc, char **argv)
 		hipStream_t s2;
 		CK(hipFuncSetAttribute((const void *) hammer, hipFuncAttributeMaxDynamicSharedMemorySize, 53248));
 		CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
-		CK(hipFuncSetAttribute((const void *) mf::ordered_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) mf::kOrderedSumLds));
+		CK(hipFuncSetAttribute((const void *) osum, hipFuncAttributeMaxDynamicSharedMemorySize, (int) mf::kOrderedSumLds));
 		size_t bad_launches = 0, bad_values = 0;
 		for (int l = 0; l < launches; ++l) {
 			if (l % 2 == 0) hammer<<<4096, 64, 53248, s2>>>(flush, flush + (fbytes / 16), fbytes / 16, 40);
 			CK(hipMemsetAsync(Xn, 0, (size_t) nrows * ld * 8, 0));
-			mf::ordered_sum_kernel<<<nrows * nsl, mf::kWave, mf::kOrderedSumLds, 0>>>(o);
+			osum<<<nrows * nsl, mf::kWave, mf::kOrderedSumLds, 0>>>(o);
 			CK(hipMemcpy(got.data(), Xn, got.size() * 8, hipMemcpyDeviceToHost));
 			size_t bad = 0;
 			for (int i = 0; i < nrows; ++i)
@@ -170,10 +173,10 @@ int main(int argc, char **argv)
 		return 0;
 	}
 	// where the time of one launch goes: clock stamps of every (row, slice) task (100 MHz wall clock)
-	CK(hipFuncSetAttribute((const void *) mf::ordered_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, mf::kOrderedSumLds));
+	CK(hipFuncSetAttribute((const void *) osum, hipFuncAttributeMaxDynamicSharedMemorySize, mf::kOrderedSumLds));
 	o.stamps = dst;
 	CK(hipMemsetAsync(flush, 7, fbytes, 0));
-	mf::ordered_sum_kernel<<<nrows * nsl, mf::kWave, mf::kOrderedSumLds, 0>>>(o);
+	osum<<<nrows * nsl, mf::kWave, mf::kOrderedSumLds, 0>>>(o);
 	CK(hipDeviceSynchronize());
 	std::vector<unsigned long long> st((size_t) nrows * nsl * 4);
 	CK(hipMemcpy(st.data(), dst, st.size() * 8, hipMemcpyDeviceToHost));
