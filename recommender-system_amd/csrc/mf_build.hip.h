@@ -363,6 +363,22 @@ int build_sparse(mf_plan *p, const mf_shard *s_in, const mf_entry *aos, bool swa
 	return MF_OK;
 }
 
+// Does the single-wave launch of this sweep take the wave-pair form (mf_sweep.hip.h: loader + compute wave per row)?  Where
+// the kernel exists (64 <= K <= 128, compile-time K) and the launch is small and skewed: at most 65536 rows, at most
+// ~2 ms of bytes, the longest row at least four times the mean -- such a launch ENDS on its long rows, which a pair walks
+// 2.4x faster than one wave.  A launch of equally long rows is faster on the single-wave form (cfg3 uniform 0.207 vs
+// 0.222 ms), and so is a large skewed one, bound by throughput rather than by its tail (the Netflix shape's item sweep,
+// 17770 rows of 3770 entries on average: 11.0 vs 14.3 ms).  MF_SWEEP_PAIR=0|1 overrides.
+bool pair_wanted(const mf_plan *p, int kind)
+{
+	if (!p->sweep.pair || p->cfg.sweep_pair == 0) return false;
+	if (p->cfg.sweep_pair == 1) return true;
+	const int nrows = kind == 0 ? p->items : p->uc;
+	if (nrows < 512 || nrows > 65536 || p->nnz <= 0) return false;
+	if ((double) p->nnz * 8.0 * p->K / 6e12 * 1e6 > 2000.0) return false;
+	return (long long) p->max_row_len[kind] >= 4 * std::max<long long>(p->nnz / nrows, 1);
+}
+
 // Schedule of the two sweeps from the row lengths: which rows count as long, whether a tiny sweep runs as ONE
 // cooperative launch, and the segment tables + scratch buffer of the extreme-row path.
 int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vector<int> &cptr)
@@ -391,9 +407,16 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 			const int nrows = kind == 0 ? p->items : p->uc;
 			// ... and only rows well above the average count as long: when every row is equally long (the cfg4
 			// twin: 1000 items x 1000 entries) there is no skew to fix and the single-wave kernel is the faster one
-			const int t_kind = cfg.sweep_long_set ? t_long : std::max(t_long, (int) std::min<long long>(4 * (long long) (p->nnz / std::max(nrows, 1)), 2000000000ll));
+			const int t_kind = cfg.sweep_long_kind[kind] > 0 ? cfg.sweep_long_kind[kind] : cfg.sweep_long_set ? t_long : std::max(t_long, (int) std::min<long long>(4 * (long long) (p->nnz / std::max(nrows, 1)), 2000000000ll));
 			if (p->max_row_len[kind] < t_kind) continue;
-			if (est_us < 50.0 && nrows < 4096 && !cfg.sweep_long_set) {
+			// With the wave-pair form a long row is walked at ~0.055 us per entry at K=100 (a lone single wave: 0.13): when
+			// even the longest row's walk fits the sweep's bandwidth time the split buys nothing and costs the scratch
+			// round trip and a fork/join (cfg3 power-law users, longest row 2324: 0.160 -> 0.139 ms without the split).
+			const bool forced_thr = cfg.sweep_long_set || cfg.sweep_long_kind[kind] > 0;
+			if (pair_wanted(p, kind) && !forced_thr && est_us >= 50.0 &&
+			    (double) p->max_row_len[kind] * 0.055 * p->K / 100.0 <= 1.3 * est_us)
+				continue;
+			if (est_us < 50.0 && nrows < 4096 && !cfg.sweep_long_set && cfg.sweep_long_kind[kind] <= 0) {
 				if (p->sweep.coop && (nc >= 8 || cfg.sweep_nch)) {
 					p->coop_all[kind] = true;
 					p->nch_coop = cfg.sweep_nch ? nl : nc;
@@ -503,11 +526,14 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 			p->scratch_entries = (size_t) scratch_entries + mf::kBlockEntries;
 			MF_TRY(dev_alloc(&p->scratch, p->scratch_entries * mf::kSliceCols *
 			                                  (size_t) ((p->K + mf::kSliceCols - 1) / mf::kSliceCols)));
-			// high priority: the ordered sums are few, latency-bound waves that must get their slots (32 KB of LDS
-			// each) ahead of the thousands of workgroups of the sweep they run under
 			int prio_lo = 0, prio_hi = 0;
 			MF_TRY_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-			MF_TRY_HIP(hipStreamCreateWithPriority(&p->side_stream, hipStreamNonBlocking, prio_hi));
+			// beside the single-wave form: high priority -- the ordered sums are few, latency-bound waves that must get their
+			// slots ahead of the thousands of workgroups of the sweep they run under.  Beside the wave-pair form: LOW
+			// priority -- there the launch ends on the pairs of the long rows, which must be dispatched at once, and the
+			// side path has the whole other sweep to hide under (cfg3 power-law 0.304 -> 0.268 ms).  MF_SIDE_PRIO=0|1.
+			const bool side_low = cfg.side_prio >= 0 ? cfg.side_prio == 0 : (pair_wanted(p, 0) || pair_wanted(p, 1));
+			MF_TRY_HIP(hipStreamCreateWithPriority(&p->side_stream, hipStreamNonBlocking, side_low ? prio_lo : prio_hi));
 			MF_TRY_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
 			MF_TRY_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
 			if (p->n_mid[0] || p->n_mid[1]) {
@@ -563,6 +589,7 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 		const int limit = p->cfg.db_rows;
 		p->use_db[kind] = p->sweep.db && !p->coop_all[kind] && !p->rest_coop && launch_rows > 0 &&
 		                  (p->cfg.sweep_db == 1 || (p->cfg.sweep_db < 0 && launch_rows <= limit));
+		p->use_pair[kind] = !p->coop_all[kind] && !p->rest_coop && !p->use_db[kind] && launch_rows > 0 && pair_wanted(p, kind);
 	}
 	// ---- a sweep of a few thousand rows is a handful of rounds of workgroups: in index order its tail is whatever
 	// long rows happen to start last.  Longest first (workgroups are dispatched in list order) the tail is made of the

@@ -24,6 +24,7 @@ struct mf_config {
 	double sweep_long = 0.0;
 	int sweep_nch = 0;                // MF_SWEEP_NCH=<1..64>: entries per chunk (0: the rule of choose_sweep)
 	int sweep_db = -1;                // MF_SWEEP_DB=0|1: intra-wave double-buffered sweep off / forced (-1: by occupancy)
+	int sweep_pair = -1;              // MF_SWEEP_PAIR=0|1: wave-pair sweep (loader + compute wave per row) off / forced (-1: by the plan)
 	int es_sw = 0;                    // MF_ES_SW=8|4|2: slice width of the resident streams launch to try first
 	bool row_pitch = true;            // MF_ROW_PITCH=0: dense device rows
 	bool resident = true;             // MF_RESIDENT=0: no single-launch loop for toy instances
@@ -48,10 +49,13 @@ struct mf_config {
 	bool rest_coop = false;           // MF_SWEEP_REST=coop
 	int es_nch = 0;                   // MF_ES_NCH: segment size of the errors launch
 	int db_rows = 0;                  // MF_SWEEP_DB_ROWS: row count below which the double-buffered sweep is chosen (0: rule)
+	int sweep_long_kind[2] = {0, 0};  // MF_SWEEP_LONG_I / MF_SWEEP_LONG_U: the extreme-row threshold of the item / user sweep alone
+	int side_prio = -1;               // MF_SIDE_PRIO=0|1: the side stream of the extreme-row path at low / high priority (-1: rule)
+	int pair_nch = 0;                 // MF_SWEEP_PAIR_NCH: chunk size of the wave-pair form (0: 32)
 	int db_nch = 0;                   // MF_SWEEP_DB_NCH: its chunk size (0: 16)
 	bool sweep_pf = true;             // MF_SWEEP_PF=0: phases A / B as hipcc schedules them (two steps per LDS round trip)
 	int sweep_prio = -1;              // MF_SWEEP_PRIO: rows at least this long run at raised wave priority (0: none, -1: rule)
-	int sweep_mid = -1;               // MF_SWEEP_MID: rows at least this long (and below the extreme threshold) get their own launch (0: none, -1: rule)
+	int sweep_mid = 0;                // MF_SWEEP_MID: rows at least this long (and below the extreme threshold) get their own launch (0: none, -1: a quarter of the threshold)
 	bool mid_coop = false;            // MF_SWEEP_MID_KERNEL=coop: the mid-length rows through the row-cooperative kernel
 	int mid_nch = 0;                  // MF_SWEEP_MID_NCH: its chunk size (0: 32 or what fits a third of the LDS)
 
@@ -74,6 +78,7 @@ struct mf_config {
 			if (n >= 1 && n <= 64) c.sweep_nch = n;
 		}
 		if ((v = getenv("MF_SWEEP_DB"))) c.sweep_db = is0(v) ? 0 : 1;
+		if ((v = getenv("MF_SWEEP_PAIR"))) c.sweep_pair = is0(v) ? 0 : 1;
 		if ((v = getenv("MF_ES_SW"))) c.es_sw = atoi(v);
 		c.row_pitch = !is0(getenv("MF_ROW_PITCH"));
 		c.resident = !is0(getenv("MF_RESIDENT"));
@@ -99,6 +104,10 @@ struct mf_config {
 		if ((v = getenv("MF_ES_NCH"))) c.es_nch = atoi(v);
 		if ((v = getenv("MF_SWEEP_DB_ROWS"))) c.db_rows = atoi(v);
 		if ((v = getenv("MF_SWEEP_DB_NCH"))) c.db_nch = atoi(v);
+		if ((v = getenv("MF_SWEEP_PAIR_NCH"))) c.pair_nch = atoi(v);
+		if ((v = getenv("MF_SWEEP_LONG_I"))) c.sweep_long_kind[0] = atoi(v);
+		if ((v = getenv("MF_SWEEP_LONG_U"))) c.sweep_long_kind[1] = atoi(v);
+		if ((v = getenv("MF_SIDE_PRIO"))) c.side_prio = is0(v) ? 0 : 1;
 		if ((v = getenv("MF_SWEEP_PF"))) c.sweep_pf = !is0(v);
 		if ((v = getenv("MF_SWEEP_PRIO"))) c.sweep_prio = atoi(v);
 		if ((v = getenv("MF_SWEEP_MID"))) c.sweep_mid = atoi(v);
@@ -120,6 +129,7 @@ struct mf_config {
 		if (sweep_long_set) add("MF_SWEEP_LONG", std::to_string(sweep_long));
 		if (sweep_nch) add("MF_SWEEP_NCH", std::to_string(sweep_nch));
 		if (sweep_db >= 0) add("MF_SWEEP_DB", std::to_string(sweep_db));
+		if (sweep_pair >= 0) add("MF_SWEEP_PAIR", std::to_string(sweep_pair));
 		if (es_sw) add("MF_ES_SW", std::to_string(es_sw));
 		if (!row_pitch) add("MF_ROW_PITCH", "0");
 		if (!resident) add("MF_RESIDENT", "0");
@@ -144,9 +154,13 @@ struct mf_config {
 		if (es_nch) add("MF_ES_NCH", std::to_string(es_nch));
 		if (db_rows) add("MF_SWEEP_DB_ROWS", std::to_string(db_rows));
 		if (db_nch) add("MF_SWEEP_DB_NCH", std::to_string(db_nch));
+		if (pair_nch) add("MF_SWEEP_PAIR_NCH", std::to_string(pair_nch));
+		if (sweep_long_kind[0]) add("MF_SWEEP_LONG_I", std::to_string(sweep_long_kind[0]));
+		if (sweep_long_kind[1]) add("MF_SWEEP_LONG_U", std::to_string(sweep_long_kind[1]));
+		if (side_prio >= 0) add("MF_SIDE_PRIO", std::to_string(side_prio));
 		if (!sweep_pf) add("MF_SWEEP_PF", "0");
 		if (sweep_prio >= 0) add("MF_SWEEP_PRIO", std::to_string(sweep_prio));
-		if (sweep_mid >= 0) add("MF_SWEEP_MID", std::to_string(sweep_mid));
+		if (sweep_mid != 0) add("MF_SWEEP_MID", std::to_string(sweep_mid));
 		if (mid_nch) add("MF_SWEEP_MID_NCH", std::to_string(mid_nch));
 		if (mid_coop) add("MF_SWEEP_MID_KERNEL", "coop");
 		return s;

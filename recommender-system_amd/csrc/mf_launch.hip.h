@@ -40,7 +40,7 @@ bool sweep_is_dma(const mf_config &cfg, int K)
 int choose_sweep(mf_plan *p)
 {
 	const int K = p->K;
-	p->sweep = SweepVariant{nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+	p->sweep = SweepVariant{nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	const bool allow_dma = !p->cfg.sweep_reg;   // MF_SWEEP_IMPL=dma (default) | reg: register-staged form only
 	if (allow_dma)
 		for (const auto &v : kDma)
@@ -91,6 +91,16 @@ int choose_sweep(mf_plan *p)
 	p->lds_bytes_few = head + (size_t) few * row_bytes;
 	MF_HIP(raise_lds_limit((const void *) p->sweep.fn, (size_t) (std::max(p->lds_bytes, p->lds_bytes_few))));
 	if (p->sweep.pf) MF_HIP(raise_lds_limit((const void *) p->sweep.pf, (size_t) (std::max(p->lds_bytes, p->lds_bytes_few))));
+	if (p->sweep.pair) {   // wave-pair form: two tiles
+		// 32-entry chunks: the loader's ~90 cycles per gathered row are what a pair is bound by, the K steps of phase A are
+		// paid per chunk -- a lone 5993-entry row: 0.526 ms at 16, 0.332 at 32; cfg3 power-law 0.311 / 0.268 / 0.314 at 24 / 32 / 40
+		int npr = p->cfg.pair_nch > 0 ? p->cfg.pair_nch : 32;
+		if (p->cfg.sweep_nch) npr = p->cfg.sweep_nch;
+		while (npr > 1 && head + 2 * (size_t) npr * row_bytes > kLdsPerCu / 2) --npr;
+		p->nch_pair = npr;
+		p->lds_bytes_pair = head + 2 * (size_t) npr * row_bytes;
+		MF_HIP(raise_lds_limit((const void *) p->sweep.pair, p->lds_bytes_pair));
+	}
 	// double-buffered form (few rows per CU: the wave hides its own gather): two tiles of nch_db rows
 	if (p->sweep.db) {
 		int ndb = p->cfg.db_nch > 0 ? p->cfg.db_nch : 16;
@@ -161,17 +171,19 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 	const bool few_rows = a.nrows < p->cfg.sweep_few;
 	const bool coop = p->coop_all[kind];
 	const bool db = !coop && p->use_db[kind];
+	const bool pair = !coop && !db && p->use_pair[kind];
 	if (few_rows) a.nch = coop ? p->nch_coop : p->nch_few;
 	if (db) a.nch = p->nch_db;
-	const size_t lds = coop ? p->lds_bytes_coop : db ? p->lds_bytes_db : (few_rows ? p->lds_bytes_few : p->lds_bytes);
+	if (pair) a.nch = p->nch_pair;
+	const size_t lds = coop ? p->lds_bytes_coop : db ? p->lds_bytes_db : pair ? p->lds_bytes_pair : (few_rows ? p->lds_bytes_few : p->lds_bytes);
 	// Accumulate form of the single-wave launch.  Up to kPfRows rows: the form whose phases keep their LDS reads in flight
 	// and whose gather issue is lean -- what a wave walking a long row alone is bound by (cfg3 uniform 0.224 -> 0.201 ms,
 	// power-law 0.367 -> 0.350, a lone 5993-entry row 1.02 -> 0.78 ms).  Larger launches are never bound by one wave and
 	// keep round 2's form (cfg4 user sweep, 1e6 rows: 11.45 vs 11.60 ms).
 	constexpr int kPfRows = 262144;
 	const SweepFn single = p->sweep.pf && p->n_short[kind] <= kPfRows && a.nrows <= kPfRows ? p->sweep.pf : p->sweep.fn;
-	const SweepFn fn = coop ? p->sweep.coop : db ? p->sweep.db : single;
-	const int block = coop ? mf::kCoopWaves * mf::kWave : mf::kWave;
+	const SweepFn fn = coop ? p->sweep.coop : db ? p->sweep.db : pair ? p->sweep.pair : single;
+	const int block = coop ? mf::kCoopWaves * mf::kWave : pair ? mf::kPairThreads : mf::kWave;
 	const int grid = std::min(a.nrows, 1 << 20);
 	TimedLaunch t{};
 	if (p->timing) {
@@ -252,6 +264,10 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 			a.nch = p->nch_coop;
 			MF_HIP(hipLaunchKernel((const void *) p->sweep.coop, dim3(std::min(a.nrows, 1 << 20)),
 			                       dim3(mf::kCoopWaves * mf::kWave), args, p->lds_bytes_coop, p->stream));
+		} else if (a.nrows > 0 && pair) {
+			a.nch = p->nch_pair;
+			MF_HIP(hipLaunchKernel((const void *) p->sweep.pair, dim3(std::min(a.nrows, 1 << 20)), dim3(mf::kPairThreads), args,
+			                       p->lds_bytes_pair, p->stream));
 		} else if (a.nrows > 0 && db) {
 			a.nch = p->nch_db;
 			MF_HIP(hipLaunchKernel((const void *) p->sweep.db, dim3(std::min(a.nrows, 1 << 20)), dim3(mf::kWave), args,

@@ -731,6 +731,179 @@ __global__ void __launch_bounds__(kWave) sweep_db_kernel(SweepArgs a)
 	}
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sweep kernel, wave-pair form: for launches that end on a few long rows (a few thousand rows, skewed lengths).
+// In-kernel clocks of one wave walking a long row alone (tools/stamps.py, K=100, 16-entry chunks; cycles per chunk):
+// gather issue 1430 (an LDS-DMA instruction costs its wave ~90 cycles), landing 370, phase A 1770, phase B 1100 --
+// the wave is bound by its own instruction stream, so neither more bytes in flight nor a second tile helps it
+// (sweep_db_kernel: no gain).  Here TWO waves own the row: wave 0 only gathers -- chunk c+1 into the other tile while
+// wave 1 computes phases A and B on chunk c -- with one s_barrier per chunk: "chunk c has landed and chunk c-1 is
+// consumed".  The row's walk costs max(issue + landing, A + B) per chunk instead of their sum, and the arithmetic is
+// wave 1's alone, in the order of sweep_dma_kernel: same bits.  Compile-time K with one DMA instruction per row
+// (64 <= K <= 128).
+// ------------------------------------------------------------------------------------------------
+template <int Q, int PF>
+__device__ __forceinline__ double phase_a_dot_ahead(const double2 *t2, const double2 *xs)
+{
+	// as phase_a_dot_pipelined, and the two products of step q+1 are formed before the two adds of step q: the chain of
+	// dependent adds never waits for a multiply
+	double2 t[PF], x[PF];
+#pragma unroll
+	for (int i = 0; i < PF; ++i)
+		if (i < Q) {
+			t[i] = t2[i];
+			x[i] = xs[i];
+		}
+	double dot = 0.0;
+	double px = x[0].x * t[0].x, py = x[0].y * t[0].y;
+#pragma unroll
+	for (int q = 0; q < Q; ++q) {
+		double nx = 0.0, ny = 0.0;
+		if (q + 1 < Q) {
+			nx = x[(q + 1) % PF].x * t[(q + 1) % PF].x;
+			ny = x[(q + 1) % PF].y * t[(q + 1) % PF].y;
+		}
+		if (q + PF < Q) {
+			t[q % PF] = t2[q + PF];
+			x[q % PF] = xs[q + PF];
+		}
+		asm volatile("" ::: "memory");
+		dot = dot + px;
+		dot = dot + py;
+		px = nx;
+		py = ny;
+	}
+	return dot;
+}
+
+constexpr int kPairThreads = 2 * kWave;
+
+template <int KT>
+__global__ void __launch_bounds__(kPairThreads) sweep_pair_kernel(SweepArgs a)
+{
+	using G = DmaGeom<KT>;
+	static_assert(G::kPasses == 1 && (G::kPieces | 1) > 32, "one LDS-DMA instruction per gathered row");
+	constexpr int P = G::kPieces, S = G::kStride;
+	extern __shared__ __attribute__((aligned(16))) char lds[];
+	double2 *xs = reinterpret_cast<double2 *>(lds);
+	char *tile0 = lds + G::kXsBytes;
+	const int nch = a.nch;
+	const int tile_bytes = nch * S;
+	const unsigned tile0_lds = (unsigned) (unsigned long long) (__attribute__((address_space(3))) char *) tile0;
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));   // scalar: the two roles never share a branch mask
+	const unsigned voff = (unsigned) lane * 16u;
+	const unsigned long long ybase = (unsigned long long) a.Y_old;
+	const unsigned long long ybytes = (unsigned long long) a.ldy * 8ull;
+
+	for (int it = blockIdx.x; it < a.nrows; it += gridDim.x) {
+		const int r = a.rowlist ? a.rowlist[it] : it;
+		const int beg = a.ptr[r], end = a.ptr[r + 1];
+		// long rows are what the launch ends on: both of their waves run at raised priority (instruction issue is
+		// arbitrated by priority, then age) beside the waves of short rows on the same SIMDs
+		const bool long_row = a.prio_len > 0 && end - beg >= a.prio_len;
+		if (wave == 0) {
+			// ---------------- loader: chunk c -> tile c & 1, then "landed" = barrier c
+			if (long_row)
+				__builtin_amdgcn_s_setprio(3);
+			else
+				__builtin_amdgcn_s_setprio(1);   // its few instructions gate the compute wave
+			int nx_idx = 0;
+			if (beg + lane < min(end, beg + nch)) nx_idx = a.idx[beg + lane];
+			int buf = 0;
+			for (int c = beg; c < end; c += nch, buf ^= 1) {
+				const int cnt = min(nch, end - c);
+				int my_idx = nx_idx;
+				asm volatile("" : "+v"(my_idx));   // hipcc's wait for this load stays here, outside the loops below
+				nx_idx = 0;
+				if (c + nch + lane < min(end, c + 2 * nch)) nx_idx = a.idx[c + nch + lane];
+				const unsigned long long rowaddr = ybase + (unsigned long long) (unsigned) my_idx * ybytes;
+				const int alo = (int) (unsigned) rowaddr, ahi = (int) (unsigned) (rowaddr >> 32);
+				const unsigned tb = tile0_lds + (unsigned) (buf * tile_bytes);
+				int n = 0;
+				for (; n + 4 <= cnt; n += 4) {
+					unsigned long long b[4];
+#pragma unroll
+					for (int u = 0; u < 4; ++u)
+						b[u] = ((unsigned long long) (unsigned) __builtin_amdgcn_readlane(ahi, n + u) << 32) |
+						       (unsigned long long) (unsigned) __builtin_amdgcn_readlane(alo, n + u);
+					if (lane < P) {
+#pragma unroll
+						for (int u = 0; u < 4; ++u)
+							asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0"
+							             :
+							             : "s"(b[u]), "s"(tb + (unsigned) ((n + u) * S)), "v"(voff)
+							             : "memory");
+					}
+				}
+				for (; n < cnt; ++n) {
+					const unsigned long long b = ((unsigned long long) (unsigned) __builtin_amdgcn_readlane(ahi, n) << 32) |
+					                             (unsigned long long) (unsigned) __builtin_amdgcn_readlane(alo, n);
+					if (lane < P)
+						asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0"
+						             :
+						             : "s"(b), "s"(tb + (unsigned) (n * S)), "v"(voff)
+						             : "memory");
+				}
+				// landed (this also retires the index load of the next chunk, issued in front of the transfers)
+				asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+			}
+			asm volatile("s_barrier" ::: "memory");   // row end: the compute wave has consumed the last tile
+		} else {
+			// ---------------- compute: phases A and B of chunk c after barrier c
+			if (long_row)
+				__builtin_amdgcn_s_setprio(3);
+			else
+				__builtin_amdgcn_s_setprio(0);
+			const double2 *__restrict__ xrow2 = reinterpret_cast<const double2 *>(a.X_old + (size_t) r * a.ldx);
+			double2 acc = make_double2(0.0, 0.0);
+			if (lane < P) {
+				const double2 v = xrow2[lane];
+				xs[lane] = v;
+				if (a.seed) acc = v;
+			}
+			double nx_val = 0.0;
+			if (beg + lane < min(end, beg + nch)) nx_val = a.val[beg + lane];
+			const unsigned boff = (unsigned) (lane < P ? lane : 0) * 16u;   // lanes beyond the row re-read piece 0: no branch masks in phase B
+			int buf = 0;
+			for (int c = beg; c < end; c += nch, buf ^= 1) {
+				const int cnt = min(nch, end - c);
+				double my_val = nx_val;
+				nx_val = 0.0;
+				if (c + nch + lane < min(end, c + 2 * nch)) nx_val = a.val[c + nch + lane];
+				asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(my_val)::"memory");   // chunk c has landed
+				const char *tile = tile0 + buf * tile_bytes;
+				const double2 *t2 = reinterpret_cast<const double2 *>(tile + (lane < nch ? lane : 0) * S);
+				const double dot = phase_a_dot_ahead<KT / 2, 8>(t2, xs);
+				const double e = a.c2 * (my_val - dot);
+				const char *tb = tile + boff;
+				int n = 0;
+				for (; n + 16 <= cnt; n += 16) {
+					double2 t[16];
+#pragma unroll
+					for (int u = 0; u < 16; ++u) t[u] = *reinterpret_cast<const double2 *>(tb + (n + u) * S);
+					asm volatile("" ::: "memory");
+#pragma unroll
+					for (int u = 0; u < 16; ++u) {
+						const double en = readlane_f64(e, n + u);
+						acc.x = acc.x + en * t[u].x;
+						acc.y = acc.y + en * t[u].y;
+					}
+				}
+				for (; n < cnt; ++n) {
+					const double en = readlane_f64(e, n);
+					const double2 t = *reinterpret_cast<const double2 *>(tb + n * S);
+					acc.x = acc.x + en * t.x;
+					acc.y = acc.y + en * t.y;
+				}
+			}
+			if (lane < P) reinterpret_cast<double2 *>(a.X_new + (size_t) r * a.ldx)[lane] = acc;
+			// row end: every read of the last tile and of xs is complete before the loader refills / xs is rewritten
+			asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+		}
+	}
+}
+
 // Ordered sum of the scaled rows of one extreme row: X_new[r][k] = (...((seed + p_0[k]) + p_1[k]) + ...), the
 // serial accumulation order.  One wave per (row, 8-column slice).  The slice is contiguous over the entries (64 B
 // each), so ONE LDS-DMA instruction brings a block of 16 consecutive entries (1 KiB) into a slot of an LDS ring and the

@@ -215,6 +215,81 @@ def test_ordered_sums_every_depth_class_with_and_without_seed(capi, orc, monkeyp
         assert np.array_equal(Ln, Lo), (k, root)
 
 
+@pytest.mark.parametrize("k", [100, 128, 64, 96])
+@pytest.mark.parametrize("nch", [None, "16", "5", "64"])
+def test_wave_pair_sweep_bit_exact(capi, orc, k, nch, monkeypatch):
+    """sweep_pair_kernel (loader wave + compute wave per row, one barrier per chunk, two tiles): forced with MF_SWEEP_PAIR=1
+    on a shape with empty rows, one-entry rows, rows of exactly one / two chunks +- 1 and a few long rows, seeded and
+    unseeded item sweeps, several iterations -- bit-exact against the oracle.  K = 64 and 96 have no compile-time
+    instance (the run-time-K single-wave form runs, the switch is ignored); 100 and 128 take the pair form."""
+    U, I = 700, 90
+    rng = np.random.default_rng(900 + k)
+    lens = rng.integers(0, 12, U)
+    lens[:40] = [0, 1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 5, 4, 3, 1, 90, 89, 88, 47, 48, 49, 0, 0, 1, 1, 2, 2, 31, 33,
+                 90, 90, 77, 76, 75, 20, 21, 22, 23, 24]
+    row = np.repeat(np.arange(U, dtype=np.int32), lens)
+    col = np.concatenate([np.sort(rng.choice(I, int(n), replace=False)) for n in lens if n] or [np.zeros(0, np.int64)]).astype(np.int32)
+    val = rng.integers(1, 6, len(row)).astype(np.float64)
+    monkeypatch.setenv("MF_SWEEP_PAIR", "1")
+    monkeypatch.setenv("MF_ITER_MODE", "sweeps")
+    if nch:
+        monkeypatch.setenv("MF_SWEEP_NCH", nch)
+    alpha = 1e-3 / k
+    d = dict(iters=4, alpha=alpha, feats=k, users=U, items=I, row=row, col=col, val=val)
+    plan = capi.Plan(U, I, k, alpha, row, col, val)
+    desc = plan.describe()
+    assert ("wave_pair=1/1" in desc) == (k in (100, 128)), desc
+    L0, R0 = capi.init_factors(U, I, k)
+    plan.upload(L0, R0)
+    plan.iterate(4)
+    L, R = plan.download()
+    Lo, Ro = L0.copy(), R0.copy()
+    orc.factorize(orc.Instance(**d), Lo, Ro)
+    assert np.array_equal(L, Lo) and np.array_equal(R, Ro), (k, nch)
+    # the sharded steps: a non-root shard's item sweep starts from zero (matFact-mpi.c:187)
+    for root in (True, False):
+        plan.upload(L0, R0)
+        plan.sweep_items(seed_from_old=root)
+        plan.sweep_users()
+        plan.flip()
+        Ln, Ra = plan.download()
+        Lo1, Rao = orc.shard_step(0, U, I, k, row, col, val, alpha, L0, R0, root)
+        assert np.array_equal(Ra, Rao) and np.array_equal(Ln, Lo1), (k, nch, root)
+    plan.close()
+
+
+def test_wave_pair_rule_and_extreme_rows_beside_it(capi, orc, monkeypatch):
+    """The plan's own choice on a small skewed instance at K=100: the item side (one item rated by everybody) keeps the
+    extreme-row path beside a wave-pair launch of the other rows, the user side (longest row walkable within the sweep's
+    time) is not split at all -- and the factors are the oracle's bits."""
+    U, I, K = 8000, 1500, 100   # 4.3e5 entries: a sweep of ~57 us of bytes (below 50 a tiny sweep takes one cooperative launch)
+    rng = np.random.default_rng(4242)
+    pop = (np.arange(I) + 1.0) ** -1.1
+    pop /= pop.sum()
+    lens = np.clip((rng.pareto(1.3, U) * 18 + 12).astype(np.int64), 4, 900)
+    rows, cols = [], []
+    for u in range(U):
+        c = np.unique(np.concatenate([[0], rng.choice(I, int(lens[u]), replace=False, p=pop)]))
+        rows.append(np.full(len(c), u, np.int32))
+        cols.append(c.astype(np.int32))
+    row, col = np.concatenate(rows), np.concatenate(cols)
+    val = rng.integers(1, 6, len(row)).astype(np.float64)
+    monkeypatch.setenv("MF_ITER_MODE", "sweeps")
+    monkeypatch.delenv("MF_SWEEP_DB", raising=False)
+    d = dict(iters=3, alpha=2e-6, feats=K, users=U, items=I, row=row, col=col, val=val)
+    plan = capi.Plan(U, I, K, d["alpha"], row, col, val)
+    desc = plan.describe()
+    assert "wave_pair=1/1" in desc and "long_rows=0/" not in desc and "/0 coop_nch" in desc, desc
+    L0, R0 = capi.init_factors(U, I, K)
+    plan.upload(L0, R0)
+    plan.iterate(3)
+    L, R = plan.download()
+    plan.close()
+    Lo, Ro = L0.copy(), R0.copy()
+    orc.factorize(orc.Instance(**d), Lo, Ro)
+    assert np.array_equal(L, Lo) and np.array_equal(R, Ro)
+
+
 def test_dispatch_order_of_a_large_skewed_sweep(capi, orc):
     """More than 32768 users, a few of them ten times longer than the average but below the extreme-row threshold:
     the user sweep runs from a row list with those rows first and the rest in index order; the item sweep (300 rows)
@@ -492,8 +567,12 @@ def test_row_cooperative_sweep_bit_exact(capi, orc, k, monkeypatch):
         plan.upload(L, R)
         plan.iterate(3)
         Lg, Rg = plan.download()
+        desc = plan.describe()
         plan.close()
-        assert np.array_equal(Lg, Lo) and np.array_equal(Rg, Ro), (k, nch)
+        bad_l, bad_r = np.where((Lg != Lo).any(axis=1))[0], np.where((Rg != Ro).any(axis=1))[0]
+        assert len(bad_l) == 0 and len(bad_r) == 0, (k, nch, desc, "L rows", bad_l[:8], "R rows", bad_r[:8],
+                                                     [np.where(Lg[x] != Lo[x])[0][:6] for x in bad_l[:3]],
+                                                     [np.where(Rg[x] != Ro[x])[0][:6] for x in bad_r[:3]])
 
 
 def test_multi_shard_item_heavy_instance_cuts_the_items(capi, orc):
