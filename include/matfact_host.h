@@ -106,12 +106,22 @@ int mf_host_checkpoint_write(const char *path, const mf_problem *p, int iters_do
 /* L (users x K) and R (items x K) must be allocated by the caller; fails (-1) if the file does not belong to p */
 int mf_host_checkpoint_read(const char *path, const mf_problem *p, int *iters_done, double *L, double *R);
 
-/* ---- synthetic instances: row u has m(u) in [min_row, max_row] distinct sorted columns, ratings in {1..5};
- * everything is a pure function of (seed, u), so any rank can generate any block of users. */
+/* ---- synthetic instances (the reference ships no generator): row u has m(u) distinct sorted columns,
+ * m(u) ~ U[min_row, max_row], ratings ~ U{1..5}; everything is a pure function of (seed, u), so any rank can generate
+ * any block of users.  target_nnz > 0 rescales the counts so that they sum to target_nnz exactly.  Columns:
+ *   MF_SYNTH_STRATIFIED  one column per stratum of width items / m(u) (rounds 1-2: every item ends up with a
+ *                        near-identical count -- the friendliest column distribution)
+ *   MF_SYNTH_UNIFORM     m(u) distinct uniform columns (the survey's headline generator)
+ *   MF_SYNTH_ZIPF        m(u) distinct columns from Zipf(1.0) item popularity, ranks scattered over the ids: the most
+ *                        popular items are rated by nearly every user (hot columns) */
+enum { MF_SYNTH_STRATIFIED = 0, MF_SYNTH_UNIFORM = 1, MF_SYNTH_ZIPF = 2 };
 typedef struct mf_synth {
 	uint64_t seed;
 	int32_t users, items;
 	int32_t min_row, max_row;
+	int32_t mode;         /* MF_SYNTH_* */
+	int32_t reserved;
+	int64_t target_nnz;   /* 0: the raw draws */
 } mf_synth;
 /* entries per user for users [u0, u0+count): counts[count]; returns their sum */
 int64_t mf_host_synth_counts(const mf_synth *s, int u0, int count, int32_t *counts);

@@ -80,7 +80,10 @@ CANDIDATE_DTYPE = np.dtype([("score", np.float64), ("best", np.int32), ("first",
 
 class Synth(C.Structure):  # mf_synth
     _fields_ = [("seed", C.c_uint64), ("users", C.c_int32), ("items", C.c_int32), ("min_row", C.c_int32),
-                ("max_row", C.c_int32)]
+                ("max_row", C.c_int32), ("mode", C.c_int32), ("reserved", C.c_int32), ("target_nnz", C.c_int64)]
+
+
+SYNTH_MODES = {"stratified": 0, "uniform": 1, "zipf": 2}
 
 
 class Rand(C.Structure):  # mf_rand
@@ -298,20 +301,22 @@ def balanced_grid(users, items, nproc):
     return int(size[0]), int(size[1])
 
 
-def synth_counts(seed, users, items, min_row, max_row, u0=0, count=None):
+def synth_counts(seed, users, items, min_row, max_row, u0=0, count=None, columns="stratified", target_nnz=0):
     count = users - u0 if count is None else count
-    s = Synth(seed, users, items, min_row, max_row)
+    s = Synth(seed, users, items, min_row, max_row, SYNTH_MODES[columns], 0, int(target_nnz))
     counts = np.empty(count, np.int32)
     total = host().mf_host_synth_counts(C.byref(s), u0, count, counts)
     return counts, int(total)
 
 
-def synth_block(seed, users, items, min_row, max_row, u0=0, count=None):
-    """(row, col, val) of users [u0, u0+count) of the synthetic instance, (row, col)-sorted."""
+def synth_block(seed, users, items, min_row, max_row, u0=0, count=None, columns="stratified", target_nnz=0):
+    """(row, col, val) of users [u0, u0+count) of the synthetic instance, (row, col)-sorted.  columns: "stratified" (one
+    column per stratum), "uniform" (distinct uniform columns) or "zipf" (Zipf(1.0) item popularity); target_nnz > 0
+    rescales the row counts so that the WHOLE instance has exactly that many entries."""
     count = users - u0 if count is None else count
-    counts, total = synth_counts(seed, users, items, min_row, max_row, u0, count)
+    counts, total = synth_counts(seed, users, items, min_row, max_row, u0, count, columns, target_nnz)
     row, col, val = np.empty(total, np.int32), np.empty(total, np.int32), np.empty(total, np.float64)
-    s = Synth(seed, users, items, min_row, max_row)
+    s = Synth(seed, users, items, min_row, max_row, SYNTH_MODES[columns], 0, int(target_nnz))
     if host().mf_host_synth_fill(C.byref(s), u0, count, counts, row, col, val) != 0:
         raise MemoryError("mf_host_synth_fill")
     return row, col, val

@@ -3,6 +3,18 @@
 
 namespace {
 
+// Host table -> device, ORDERED WITH THE PLAN'S STREAM.  The plan's stream is created hipStreamNonBlocking: nothing
+// orders it with the null stream that a plain hipMemcpy / hipMemset uses, so every set-up transfer goes through the
+// plan's own stream and is complete (the host vector may go out of scope) when this returns.  (Round 3: three flaky
+// mismatches in the GPU suite, never reproducible alone, all on plans whose set-up mixed the two streams.)
+inline hipError_t h2d(mf_plan *p, void *dst, const void *src, size_t bytes)
+{
+	if (bytes == 0) return hipSuccess;
+	const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, p->stream);
+	return e != hipSuccess ? e : hipStreamSynchronize(p->stream);
+}
+
+
 // inside helpers that return a status directly
 #define MF_TRY(x)                       \
 	do {                                \
@@ -321,7 +333,7 @@ int build_sparse(mf_plan *p, const mf_shard *s_in, const mf_entry *aos, bool swa
 		MF_TRY(dev_alloc(&p->csr_ptr, (size_t) p->uc + 1));
 		MF_TRY(dev_alloc(&p->csr_idx, nz + 64));
 		MF_TRY(dev_alloc(&p->csr_val, nz + 64));
-		MF_TRY_HIP(hipMemcpy(p->csr_ptr, rptr.data(), ((size_t) p->uc + 1) * sizeof(int), hipMemcpyHostToDevice));
+		MF_TRY_HIP(h2d(p, p->csr_ptr, rptr.data(), ((size_t) p->uc + 1) * sizeof(int)));
 		{
 			// mask ids ascending inside every row (see build_on_device) when the file order is not
 			bool ascending = true;
@@ -331,12 +343,12 @@ int build_sparse(mf_plan *p, const mf_shard *s_in, const mf_entry *aos, bool swa
 				std::vector<int> mk(idx);
 				for (int u = 0; u < p->uc; ++u) std::sort(mk.begin() + rptr[(size_t) u], mk.begin() + rptr[(size_t) u + 1]);
 				MF_TRY(dev_alloc(&p->mask_idx, nz + 64));
-				MF_TRY_HIP(hipMemcpy(p->mask_idx, mk.data(), nz * sizeof(int), hipMemcpyHostToDevice));
+				MF_TRY_HIP(h2d(p, p->mask_idx, mk.data(), nz * sizeof(int)));
 			}
 		}
 		if (nz) {
-			MF_TRY_HIP(hipMemcpy(p->csr_idx, idx.data(), nz * sizeof(int), hipMemcpyHostToDevice));
-			MF_TRY_HIP(hipMemcpy(p->csr_val, val.data(), nz * sizeof(double), hipMemcpyHostToDevice));
+			MF_TRY_HIP(h2d(p, p->csr_idx, idx.data(), nz * sizeof(int)));
+			MF_TRY_HIP(h2d(p, p->csr_val, val.data(), nz * sizeof(double)));
 		}
 		try {
 			bucket(s->nnz, p->items, s->col, 0, s->row, p->u0, s->val, cptr, idx, val, p->want_map ? &pos_c : nullptr);
@@ -346,16 +358,16 @@ int build_sparse(mf_plan *p, const mf_shard *s_in, const mf_entry *aos, bool swa
 		MF_TRY(dev_alloc(&p->csc_ptr, (size_t) p->items + 1));
 		MF_TRY(dev_alloc(&p->csc_idx, nz + 64));
 		MF_TRY(dev_alloc(&p->csc_val, nz + 64));
-		MF_TRY_HIP(hipMemcpy(p->csc_ptr, cptr.data(), ((size_t) p->items + 1) * sizeof(int), hipMemcpyHostToDevice));
+		MF_TRY_HIP(h2d(p, p->csc_ptr, cptr.data(), ((size_t) p->items + 1) * sizeof(int)));
 		if (nz) {
-			MF_TRY_HIP(hipMemcpy(p->csc_idx, idx.data(), nz * sizeof(int), hipMemcpyHostToDevice));
-			MF_TRY_HIP(hipMemcpy(p->csc_val, val.data(), nz * sizeof(double), hipMemcpyHostToDevice));
+			MF_TRY_HIP(h2d(p, p->csc_idx, idx.data(), nz * sizeof(int)));
+			MF_TRY_HIP(h2d(p, p->csc_val, val.data(), nz * sizeof(double)));
 		}
 		if (p->want_map) {
 			std::vector<int> map(nz + 1);
 			for (size_t n = 0; n < nz; ++n) map[(size_t) pos_r[n]] = pos_c[n];
 			MF_TRY(dev_alloc(&p->csr2csc, nz + 64));
-			if (nz) MF_TRY_HIP(hipMemcpy(p->csr2csc, map.data(), nz * sizeof(int), hipMemcpyHostToDevice));
+			if (nz) MF_TRY_HIP(h2d(p, p->csr2csc, map.data(), nz * sizeof(int)));
 		}
 	} else {
 		MF_TRY(build_on_device(p, s_in, aos, swap, rptr, cptr));
@@ -460,14 +472,14 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 			}
 			if (!md.empty()) {
 				MF_TRY(dev_alloc(&p->mid_rows[kind], md.size()));
-				MF_TRY_HIP(hipMemcpy(p->mid_rows[kind], md.data(), md.size() * sizeof(int), hipMemcpyHostToDevice));
+				MF_TRY_HIP(h2d(p, p->mid_rows[kind], md.data(), md.size() * sizeof(int)));
 				p->n_mid[kind] = (int) md.size();
 			}
 			MF_TRY(dev_alloc(&p->long_rows[kind], lg.size()));
 			MF_TRY(dev_alloc(&p->short_rows[kind], sh.size()));
-			MF_TRY_HIP(hipMemcpy(p->long_rows[kind], lg.data(), lg.size() * sizeof(int), hipMemcpyHostToDevice));
+			MF_TRY_HIP(h2d(p, p->long_rows[kind], lg.data(), lg.size() * sizeof(int)));
 			if (!sh.empty())
-				MF_TRY_HIP(hipMemcpy(p->short_rows[kind], sh.data(), sh.size() * sizeof(int), hipMemcpyHostToDevice));
+				MF_TRY_HIP(h2d(p, p->short_rows[kind], sh.data(), sh.size() * sizeof(int)));
 			p->n_long[kind] = (int) lg.size();
 			p->long_len[kind] = t_eff;
 			p->n_short[kind] = (int) sh.size();
@@ -499,12 +511,12 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 			MF_TRY(dev_alloc(&p->seg_out[kind], srow.size()));
 			MF_TRY(dev_alloc(&p->lr_sbeg[kind], lg.size()));
 			MF_TRY(dev_alloc(&p->lr_cnt[kind], lg.size()));
-			MF_TRY_HIP(hipMemcpy(p->seg_row[kind], srow.data(), srow.size() * sizeof(int), hipMemcpyHostToDevice));
-			MF_TRY_HIP(hipMemcpy(p->seg_beg[kind], sbeg.data(), srow.size() * sizeof(int), hipMemcpyHostToDevice));
-			MF_TRY_HIP(hipMemcpy(p->seg_end[kind], send.data(), srow.size() * sizeof(int), hipMemcpyHostToDevice));
-			MF_TRY_HIP(hipMemcpy(p->seg_out[kind], sout.data(), srow.size() * sizeof(long long), hipMemcpyHostToDevice));
-			MF_TRY_HIP(hipMemcpy(p->lr_sbeg[kind], lbeg.data(), lg.size() * sizeof(long long), hipMemcpyHostToDevice));
-			MF_TRY_HIP(hipMemcpy(p->lr_cnt[kind], lcnt.data(), lg.size() * sizeof(int), hipMemcpyHostToDevice));
+			MF_TRY_HIP(h2d(p, p->seg_row[kind], srow.data(), srow.size() * sizeof(int)));
+			MF_TRY_HIP(h2d(p, p->seg_beg[kind], sbeg.data(), srow.size() * sizeof(int)));
+			MF_TRY_HIP(h2d(p, p->seg_end[kind], send.data(), srow.size() * sizeof(int)));
+			MF_TRY_HIP(h2d(p, p->seg_out[kind], sout.data(), srow.size() * sizeof(long long)));
+			MF_TRY_HIP(h2d(p, p->lr_sbeg[kind], lbeg.data(), lg.size() * sizeof(long long)));
+			MF_TRY_HIP(h2d(p, p->lr_cnt[kind], lcnt.data(), lg.size() * sizeof(int)));
 		}
 		if (p->coop_all[0] || p->coop_all[1])
 			MF_TRY_HIP(raise_lds_limit((const void *) p->sweep.coop, p->lds_bytes_coop));
@@ -618,7 +630,7 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 				order.insert(order.begin(), head.begin(), head.end());
 			}
 			MF_TRY(dev_alloc(&p->short_rows[kind], order.size()));
-			MF_TRY_HIP(hipMemcpy(p->short_rows[kind], order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
+			MF_TRY_HIP(h2d(p, p->short_rows[kind], order.data(), order.size() * sizeof(int)));
 			p->lpt[kind] = true;
 		}
 	return MF_OK;
@@ -655,13 +667,14 @@ int plan_es_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vector
 	MF_TRY(dev_alloc(&p->es_seg_end, srow.size()));
 	MF_TRY(dev_alloc(&p->rec_csr, (size_t) p->nnz + 64));
 	MF_TRY(dev_alloc(&p->rec_csc, (size_t) p->nnz + 64));
-	MF_TRY_HIP(hipMemcpy(p->es_seg_row, srow.data(), srow.size() * sizeof(int), hipMemcpyHostToDevice));
-	MF_TRY_HIP(hipMemcpy(p->es_seg_beg, sbeg.data(), srow.size() * sizeof(int), hipMemcpyHostToDevice));
-	MF_TRY_HIP(hipMemcpy(p->es_seg_end, send.data(), srow.size() * sizeof(int), hipMemcpyHostToDevice));
+	MF_TRY_HIP(h2d(p, p->es_seg_row, srow.data(), srow.size() * sizeof(int)));
+	MF_TRY_HIP(h2d(p, p->es_seg_beg, sbeg.data(), srow.size() * sizeof(int)));
+	MF_TRY_HIP(h2d(p, p->es_seg_end, send.data(), srow.size() * sizeof(int)));
 	// records = {idx (fixed), pad, err (rewritten every iteration)}; the 64 entries of slack behind the last one are
 	// read (never used) by the streams launch's 64-wide chunk loads
-	MF_TRY_HIP(hipMemset(p->rec_csr, 0, ((size_t) p->nnz + 64) * sizeof(mf::StreamRec)));
-	MF_TRY_HIP(hipMemset(p->rec_csc, 0, ((size_t) p->nnz + 64) * sizeof(mf::StreamRec)));
+	// on the plan's own stream: it is a non-blocking stream, NOT ordered with the null stream a plain hipMemset runs on
+	MF_TRY_HIP(hipMemsetAsync(p->rec_csr, 0, ((size_t) p->nnz + 64) * sizeof(mf::StreamRec), p->stream));
+	MF_TRY_HIP(hipMemsetAsync(p->rec_csc, 0, ((size_t) p->nnz + 64) * sizeof(mf::StreamRec), p->stream));
 	{
 		const unsigned grid = (unsigned) ((p->nnz + 255) / 256);
 		hipLaunchKernelGGL(fill_records_kernel, dim3(grid), dim3(256), 0, p->stream, p->csr_idx, p->nnz, p->rec_csr);
@@ -720,7 +733,7 @@ int plan_es_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vector
 		p->res_lds = (size_t) std::max(p->uc, p->items) * sw * 8 + mf::kResidentWaves * mf::kResidentWaveLds;
 		if (p->res_nwg > 0) {
 			MF_TRY(dev_alloc(&p->res_wg, wgs.size()));
-			MF_TRY_HIP(hipMemcpy(p->res_wg, wgs.data(), wgs.size() * sizeof(mf::SliceWg), hipMemcpyHostToDevice));
+			MF_TRY_HIP(h2d(p, p->res_wg, wgs.data(), wgs.size() * sizeof(mf::SliceWg)));
 			const void *fn = sw == 8   ? (const void *) mf::stream_resident_kernel<8>
 			                 : sw == 4 ? (const void *) mf::stream_resident_kernel<4>
 			                           : (const void *) mf::stream_resident_kernel<2>;

@@ -143,8 +143,8 @@ static int plan_create_impl(mf_plan **out, const mf_shard *s, const mf_entry *ao
 		MF_TRY(dev_alloc(&p->Lbuf[0], nl));
 		MF_TRY(dev_alloc(&p->Lbuf[1], nl));
 		if (p->ldl != p->K) {   // the padding is never read by a kernel, but it is summed by the multi-GPU reducers
-			MF_TRY_HIP(hipMemset(p->Lbuf[0], 0, std::max<size_t>(nl, 1) * sizeof(double)));
-			MF_TRY_HIP(hipMemset(p->Lbuf[1], 0, std::max<size_t>(nl, 1) * sizeof(double)));
+			MF_TRY_HIP(hipMemsetAsync(p->Lbuf[0], 0, std::max<size_t>(nl, 1) * sizeof(double), p->stream));
+			MF_TRY_HIP(hipMemsetAsync(p->Lbuf[1], 0, std::max<size_t>(nl, 1) * sizeof(double), p->stream));
 		}
 	}
 	if (s->items_ext[0] && s->items_ext[1]) {
@@ -155,10 +155,11 @@ static int plan_create_impl(mf_plan **out, const mf_shard *s, const mf_entry *ao
 		MF_TRY(dev_alloc(&p->Rbuf[0], nr));
 		MF_TRY(dev_alloc(&p->Rbuf[1], nr));
 		if (p->ldr != p->K) {
-			MF_TRY_HIP(hipMemset(p->Rbuf[0], 0, std::max<size_t>(nr, 1) * sizeof(double)));
-			MF_TRY_HIP(hipMemset(p->Rbuf[1], 0, std::max<size_t>(nr, 1) * sizeof(double)));
+			MF_TRY_HIP(hipMemsetAsync(p->Rbuf[0], 0, std::max<size_t>(nr, 1) * sizeof(double), p->stream));
+			MF_TRY_HIP(hipMemsetAsync(p->Rbuf[1], 0, std::max<size_t>(nr, 1) * sizeof(double), p->stream));
 		}
 	}
+	MF_TRY_HIP(hipStreamSynchronize(p->stream));   // the plan is complete when the call returns
 	MF_TRY(dev_alloc(&p->best_dev, (size_t) p->uc));
 	MF_TRY(dev_alloc(&p->lnorm, (size_t) p->uc));
 	MF_TRY(dev_alloc(&p->rmax_bits, 1));
@@ -808,6 +809,19 @@ int mf_backend_recommend(const mf_problem *pr, const double *L, const double *R,
 	mf_plan_destroy(p);
 	return rc;
 }
+
+#ifdef MF_OS_DIAG
+// diagnostic build only: read and clear the records of ordered_sum_task_diag (tools/os_diag.py)
+int mf_debug_read_os_diag(unsigned long long *out, int words)
+{
+	static unsigned long long zero[2 + 8 * 32];
+	if (words > (int) (sizeof zero / sizeof zero[0])) words = (int) (sizeof zero / sizeof zero[0]);
+	MF_HIP(hipDeviceSynchronize());
+	MF_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(mf::mf_os_diag), sizeof(unsigned long long) * (size_t) words));
+	MF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(mf::mf_os_diag), zero, sizeof zero));
+	return MF_OK;
+}
+#endif
 
 #ifdef MF_STAMPS
 // diagnostic build only: read and clear the phase clocks of sweep_dma_kernel (tools/stamps.py)

@@ -1091,6 +1091,144 @@ __device__ __forceinline__ void ordered_sum_task(const char *src, unsigned ring_
 	if (b == 0) read_seed();
 	for (; b < nblk; ++b) add_block(b, min(EB, cnt - EB * b), std::integral_constant<int, -1>{}, -1);
 }
+#ifdef MF_OS_DIAG
+// Diagnostic build only (make csrc/libmatfact_hip_osdiag.so; tools/os_diag.py): ROUND 2'S LOOP ORDER -- the LDS read of
+// block b+1 issued before the v_fmac_f64_dpp chain of block b and waited for after it, the order that produced one wrong
+// entry per ~1e8 blocks -- with two checks after every chain, to tell which of the candidate causes it is:
+//   bit 0  the register the chain consumed differs from what the block's LDS slot holds NOW (re-read after the chain):
+//          the read returned before the transfer had landed, or returned something else than the slot's bytes;
+//   bit 1  the chain's result differs from the same 16 adds formed without DPP from the SAME register (lane e of the
+//          row fetched by ds_bpermute): the DPP chain mis-executed.
+// Neither bit set on a launch whose result is wrong: the slot itself held wrong bytes (the scratch as this wave's
+// transfers saw it).  mf_os_diag: [0] blocks checked, [1] records, then 8 words per record.
+__device__ unsigned long long mf_os_diag[2 + 8 * 32];
+
+template <int D>
+__device__ __forceinline__ void ordered_sum_task_diag(const char *src, unsigned ring_base, unsigned my, int cnt,
+                                                      const double *seed_ptr, double &ax, double &ay, double one, int task)
+{
+	constexpr int EB = kBlockEntries;
+	const int nblk = (cnt + EB - 1) / EB;
+	const int lane = threadIdx.x;
+	auto slot_of = [&](int b) { return (unsigned) (b & (kRing - 1)) * 1024u; };
+	auto issue = [&](int b) {
+		const char *g = src + (size_t) b * 1024;
+		const unsigned m0 = __builtin_amdgcn_readfirstlane(ring_base + slot_of(b));
+		asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0) : "memory");
+	};
+	auto read_block = [&](int b, v2d &v) {
+		const unsigned addr = my + slot_of(b);
+		asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+	};
+	auto landed = [&](v2d &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)::"memory"); };
+	auto add16 = [&](const v2d &v) {
+		MF_FMAC_BCAST(0); MF_FMAC_BCAST(1); MF_FMAC_BCAST(2); MF_FMAC_BCAST(3);
+		MF_FMAC_BCAST(4); MF_FMAC_BCAST(5); MF_FMAC_BCAST(6); MF_FMAC_BCAST(7);
+		MF_FMAC_BCAST(8); MF_FMAC_BCAST(9); MF_FMAC_BCAST(10); MF_FMAC_BCAST(11);
+		MF_FMAC_BCAST(12); MF_FMAC_BCAST(13); MF_FMAC_BCAST(14); MF_FMAC_BCAST(15);
+	};
+	auto checked_add16 = [&](int blk, const v2d &v) {
+		const double bx = ax, by = ay;
+		add16(v);
+		// (bit 1) the same sixteen adds without DPP, from the same register
+		double px = bx, py = by;
+#pragma unroll
+		for (int e = 0; e < 16; ++e) {
+			px = px + __shfl(v.x, (lane & ~15) + e);
+			py = py + __shfl(v.y, (lane & ~15) + e);
+		}
+		// (bit 0) the slot again, now that the chain is over (it is refilled one step later at the earliest)
+		v2d chk;
+		const unsigned addr = my + slot_of(blk);
+		asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(chk) : "v"(addr) : "memory");
+		int flags = 0;
+		if (__double_as_longlong(chk.x) != __double_as_longlong(v.x) || __double_as_longlong(chk.y) != __double_as_longlong(v.y)) flags |= 1;
+		if (__double_as_longlong(px) != __double_as_longlong(ax) || __double_as_longlong(py) != __double_as_longlong(ay)) flags |= 2;
+		if (lane == 0) atomicAdd(&mf_os_diag[0], 1ull);
+		if (flags) {
+			const unsigned long long slot = atomicAdd(&mf_os_diag[1], 1ull);
+			if (slot < 32) {
+				unsigned long long *r = mf_os_diag + 2 + 8 * slot;
+				r[0] = (unsigned long long) task;
+				r[1] = (unsigned long long) blk | ((unsigned long long) nblk << 32);
+				r[2] = (unsigned long long) lane | ((unsigned long long) flags << 32) | ((unsigned long long) D << 40);
+				r[3] = (unsigned long long) __double_as_longlong(v.x);
+				r[4] = (unsigned long long) __double_as_longlong(chk.x);
+				r[5] = (unsigned long long) __double_as_longlong(ax);
+				r[6] = (unsigned long long) __double_as_longlong(px);
+				r[7] = (unsigned long long) __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+			}
+		}
+	};
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	if (seed_ptr) {
+		const unsigned m0 = __builtin_amdgcn_readfirstlane(ring_base + (unsigned) kRing * 1024u);
+		asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(seed_ptr), "s"(m0) : "memory");
+	}
+	auto read_seed = [&]() {
+		v2d sv = {0.0, 0.0};
+		if (seed_ptr) {
+			const unsigned addr = my + (unsigned) kRing * 1024u;
+			asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(sv) : "v"(addr) : "memory");
+		}
+		ax = sv.x;
+		ay = sv.y;
+	};
+	const int ahead = min(nblk, D - 1);
+	for (int b = 0; b < ahead; ++b) issue(b);
+	int b = 0;
+	if (nblk > D - 1) {
+		v2d cur, nxt;
+		asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 2) : "memory");
+		read_seed();
+		read_block(0, cur);
+		auto step = [&](int blk, v2d &have, v2d &want) {   // round 2's failing order
+			landed(have);
+			asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 3) : "memory");
+			read_block(blk + 1, want);   // in flight under the chain below
+			checked_add16(blk, have);
+			issue(blk + D - 1);
+		};
+		for (; b + D < nblk; b += 2) {
+			step(b, cur, nxt);
+			step(b + 1, nxt, cur);
+		}
+		if (b + (D - 1) < nblk) {
+			step(b, cur, nxt);
+			cur = nxt;
+			++b;
+		}
+		landed(cur);
+		add16(cur);
+		++b;
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	} else {
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		read_seed();
+	}
+	for (; b < nblk; ++b) {
+		v2d v;
+		asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(my + slot_of(b)) : "memory");
+		const int n = min(EB, cnt - EB * b);
+		if (n > 0) MF_FMAC_BCAST(0);
+		if (n > 1) MF_FMAC_BCAST(1);
+		if (n > 2) MF_FMAC_BCAST(2);
+		if (n > 3) MF_FMAC_BCAST(3);
+		if (n > 4) MF_FMAC_BCAST(4);
+		if (n > 5) MF_FMAC_BCAST(5);
+		if (n > 6) MF_FMAC_BCAST(6);
+		if (n > 7) MF_FMAC_BCAST(7);
+		if (n > 8) MF_FMAC_BCAST(8);
+		if (n > 9) MF_FMAC_BCAST(9);
+		if (n > 10) MF_FMAC_BCAST(10);
+		if (n > 11) MF_FMAC_BCAST(11);
+		if (n > 12) MF_FMAC_BCAST(12);
+		if (n > 13) MF_FMAC_BCAST(13);
+		if (n > 14) MF_FMAC_BCAST(14);
+		if (n > 15) MF_FMAC_BCAST(15);
+	}
+}
+#endif
 #undef MF_FMAC_BCAST
 
 template <bool DPP>
@@ -1120,6 +1258,16 @@ __global__ void __launch_bounds__(kWave) ordered_sum_kernel(OrderedSumArgs a)
 		// every lane a valid address (the dead lanes of the last slice fetch column 0; they never store)
 		const double *seed_ptr = a.seed ? a.X_old + (size_t) r * a.ldx + (live ? k0 : 0) : nullptr;
 		double ax = 0.0, ay = 0.0;
+#ifdef MF_OS_DIAG
+		if constexpr (DPP) {
+			if (4 * (long long) cnt >= 2 * (long long) a.max_cnt)
+				ordered_sum_task_diag<kRing>(src, ring_base, my, cnt, seed_ptr, ax, ay, one, it);
+			else if (4 * (long long) cnt >= (long long) a.max_cnt)
+				ordered_sum_task_diag<kRing / 2>(src, ring_base, my, cnt, seed_ptr, ax, ay, one, it);
+			else
+				ordered_sum_task_diag<kRing / 4>(src, ring_base, my, cnt, seed_ptr, ax, ay, one, it);
+		} else
+#endif
 		// in flight: all of the ring for the longest rows, a half or a quarter of it for the shorter ones
 		if (4 * (long long) cnt >= 2 * (long long) a.max_cnt)
 			ordered_sum_task<kRing, DPP>(src, ring_base, my, cnt, seed_ptr, ax, ay, one, t_issued);

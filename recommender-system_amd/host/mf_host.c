@@ -753,7 +753,7 @@ static inline uint64_t row_state(const mf_synth *s, int u)
 	return x;
 }
 
-static inline int32_t row_count(const mf_synth *s, int u)
+static inline int32_t raw_count(const mf_synth *s, int u)
 {
 	uint64_t x = row_state(s, u);
 	const uint64_t span = (uint64_t) (s->max_row - s->min_row + 1);
@@ -763,19 +763,155 @@ static inline int32_t row_count(const mf_synth *s, int u)
 	return (int32_t) m;
 }
 
+/* target_nnz > 0: the raw draws m(u) ~ U[min_row, max_row] are rescaled so that they sum to target_nnz EXACTLY
+ * (SURVEY 8d): with C(u) the prefix sum of the raw draws and S their total, m'(u) = floor(C(u+1) T / S) - floor(C(u) T / S)
+ * -- a pure function of (seed, u) again, within one of m(u) T / S, clamped to the item count (the clamp can only bite
+ * when rows are nearly full; the generators below are not meant for that).  Costs one O(users) pass per call. */
 int64_t mf_host_synth_counts(const mf_synth *s, int u0, int count, int32_t *counts)
 {
 	int64_t total = 0;
-	#pragma omp parallel for schedule(static) reduction(+ : total)
+	if (s->target_nnz <= 0) {
+		#pragma omp parallel for schedule(static) reduction(+ : total)
+		for (int i = 0; i < count; i++) {
+			counts[i] = raw_count(s, u0 + i);
+			total += counts[i];
+		}
+		return total;
+	}
+	int64_t before = 0, all = 0;
+	#pragma omp parallel for schedule(static) reduction(+ : before, all)
+	for (int u = 0; u < s->users; u++) {
+		const int32_t m = raw_count(s, u);
+		all += m;
+		if (u < u0) before += m;
+	}
+	if (all <= 0) {
+		memset(counts, 0, sizeof(int32_t) * (size_t) count);
+		return 0;
+	}
+	/* sequential prefix over the block (cheap: one draw per user); products stay below 2^63 up to ~9e18 */
+	int64_t c = before;
 	for (int i = 0; i < count; i++) {
-		counts[i] = row_count(s, u0 + i);
-		total += counts[i];
+		const int64_t lo = (int64_t) ((__int128) c * s->target_nnz / all);
+		c += raw_count(s, u0 + i);
+		const int64_t hi = (int64_t) ((__int128) c * s->target_nnz / all);
+		int64_t m = hi - lo;
+		if (m > s->items) m = s->items;
+		counts[i] = (int32_t) m;
+		total += m;
 	}
 	return total;
 }
 
-/* Row u: m strata of [0, items), one uniformly drawn column in each -> m distinct ascending columns with a
- * uniform column marginal; rating uniform in {1,...,5}. */
+/* ---- column draws.  MF_SYNTH_STRATIFIED: row u takes one column in each of its m strata of [0, items) (round 1-2's
+ * generator: distinct, ascending, uniform marginal, every item ends up with a near-identical count).
+ * MF_SYNTH_UNIFORM: m DISTINCT columns drawn uniformly (SURVEY 8d's headline generator).  MF_SYNTH_ZIPF: m distinct
+ * columns drawn from Zipf(1.0) item popularity, P(rank r) ~ 1 / (r + 1), ranks scattered over the ids by a fixed
+ * bijection -- the most popular items are rated by (nearly) every user: hot columns. */
+static int cmp_i32(const void *a, const void *b)
+{
+	const int32_t x = *(const int32_t *) a, y = *(const int32_t *) b;
+	return (x > y) - (x < y);
+}
+
+/* Zipf(1.0) CDF over the ranks, built once per item count */
+static double *g_zipf_cdf;
+static int32_t g_zipf_items;
+static pthread_mutex_t g_zipf_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static const double *zipf_cdf(int32_t items)
+{
+	pthread_mutex_lock(&g_zipf_mu);
+	if (g_zipf_items != items) {
+		free(g_zipf_cdf);
+		g_zipf_cdf = malloc(sizeof(double) * (size_t) (items > 0 ? items : 1));
+		g_zipf_items = g_zipf_cdf ? items : 0;
+		if (g_zipf_cdf) {
+			double acc = 0.0;
+			for (int32_t r = 0; r < items; r++) {
+				acc += 1.0 / (double) (r + 1);
+				g_zipf_cdf[r] = acc;
+			}
+			for (int32_t r = 0; r < items; r++) g_zipf_cdf[r] /= acc;
+		}
+	}
+	const double *t = g_zipf_cdf;
+	pthread_mutex_unlock(&g_zipf_mu);
+	return t;
+}
+
+static inline int32_t zipf_rank(const double *cdf, int32_t items, uint64_t z)
+{
+	const double u = (double) (z >> 11) * (1.0 / 9007199254740992.0);   /* [0, 1) */
+	int32_t lo = 0, hi = items - 1;
+	while (lo < hi) {
+		const int32_t mid = lo + (hi - lo) / 2;
+		if (cdf[mid] > u)
+			hi = mid;
+		else
+			lo = mid + 1;
+	}
+	return lo;
+}
+
+/* rank -> item id: a bijection of [0, items) that scatters the popular ranks (multiplier coprime with items) */
+static inline int32_t scatter(int64_t r, int32_t items, int64_t mult, int64_t shift)
+{
+	return (int32_t) ((r * mult + shift) % items);
+}
+
+static int64_t coprime_multiplier(int32_t items)
+{
+	int64_t a = (int64_t) (0.6180339887 * (double) items) | 1;
+	for (;; a += 2) {
+		int64_t x = a, y = items;
+		while (y) {
+			const int64_t t = x % y;
+			x = y;
+			y = t;
+		}
+		if (x == 1) return a;
+	}
+}
+
+/* m distinct draws into out[0..m), ascending: draw what is missing, sort, drop duplicates, repeat (uniform draws over
+ * 1e5 items: a duplicate every ~20 rows; Zipf: a handful of rounds).  More than half of the items: the complement. */
+static void draw_distinct(const mf_synth *s, uint64_t *x, int64_t m, int32_t *out, const double *cdf, int64_t mult,
+                          int64_t shift)
+{
+	const int32_t items = s->items;
+	if (m <= 0) return;
+	if (s->mode == MF_SYNTH_UNIFORM && 2 * m > items) {   /* choose the items LEFT OUT */
+		const int64_t k = items - m;
+		int32_t *skip = malloc(sizeof(int32_t) * (size_t) (k > 0 ? k : 1));
+		if (!skip) abort();
+		mf_synth sub = *s;
+		draw_distinct(&sub, x, k, skip, cdf, mult, shift);   /* k <= items / 2: no further recursion */
+		int64_t o = 0, q = 0;
+		for (int32_t j = 0; j < items; j++) {
+			if (q < k && skip[q] == j)
+				++q;
+			else
+				out[o++] = j;
+		}
+		free(skip);
+		return;
+	}
+	int64_t have = 0;
+	while (have < m) {
+		for (int64_t t = have; t < m; t++) {
+			const uint64_t z = splitmix64(x);
+			out[t] = s->mode == MF_SYNTH_ZIPF ? scatter(zipf_rank(cdf, items, z), items, mult, shift)
+			                                  : (int32_t) ((z >> 8) % (uint64_t) items);
+		}
+		qsort(out, (size_t) m, sizeof(int32_t), cmp_i32);
+		int64_t w = 0;
+		for (int64_t t = 0; t < m; t++)
+			if (w == 0 || out[t] != out[w - 1]) out[w++] = out[t];
+		have = w;
+	}
+}
+
 int mf_host_synth_fill(const mf_synth *s, int u0, int count, const int32_t *counts, int32_t *row,
                        int32_t *col, double *val)
 {
@@ -783,19 +919,35 @@ int mf_host_synth_fill(const mf_synth *s, int u0, int count, const int32_t *coun
 	if (!off) return -1;
 	off[0] = 0;
 	for (int i = 0; i < count; i++) off[i + 1] = off[i] + counts[i];
+	const double *cdf = s->mode == MF_SYNTH_ZIPF ? zipf_cdf(s->items) : NULL;
+	if (s->mode == MF_SYNTH_ZIPF && !cdf) {
+		free(off);
+		return -1;
+	}
+	const int64_t mult = s->items > 1 ? coprime_multiplier(s->items) : 1;
+	const int64_t shift = s->items > 0 ? (int64_t) ((s->seed * 0x9E3779B97F4A7C15ull) >> 33) % s->items : 0;
 	#pragma omp parallel for schedule(dynamic, 1024)
 	for (int i = 0; i < count; i++) {
 		const int u = u0 + i;
 		uint64_t x = row_state(s, u);
-		(void) splitmix64(&x);   /* the draw that fixed the count */
+		(void) splitmix64(&x);   /* the draw that fixed the (raw) count */
 		const int64_t m = counts[i];
 		int64_t o = off[i];
+		if (s->mode == MF_SYNTH_STRATIFIED) {
+			/* m strata of [0, items), one uniformly drawn column in each; rating uniform in {1,...,5} */
+			for (int64_t t = 0; t < m; t++, o++) {
+				const int64_t lo = t * s->items / m, hi = (t + 1) * s->items / m;
+				const uint64_t z = splitmix64(&x);
+				row[o] = u;
+				col[o] = (int32_t) (lo + (int64_t) ((z >> 8) % (uint64_t) (hi - lo)));
+				val[o] = (double) (1 + (int) (z & 0xff) % 5);
+			}
+			continue;
+		}
+		draw_distinct(s, &x, m, col + o, cdf, mult, shift);
 		for (int64_t t = 0; t < m; t++, o++) {
-			const int64_t lo = t * s->items / m, hi = (t + 1) * s->items / m;
-			const uint64_t z = splitmix64(&x);
 			row[o] = u;
-			col[o] = (int32_t) (lo + (int64_t) ((z >> 8) % (uint64_t) (hi - lo)));
-			val[o] = (double) (1 + (int) (z & 0xff) % 5);
+			val[o] = (double) (1 + (int) (splitmix64(&x) % 5));
 		}
 	}
 	free(off);

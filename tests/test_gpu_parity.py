@@ -962,9 +962,11 @@ def test_cfg3_ml1m_shaped_full_size_bit_exact(capi, orc, skew):
     import bench
     cfg = bench.CONFIGS["cfg3"]
     U, I, K = cfg["users"], cfg["items"], cfg["feats"]
-    row, col, val = capi.synth_block(cfg["seed"], U, I, cfg["min_row"], cfg["max_row"])
+    row, col, val = capi.synth_block(cfg["seed"], U, I, cfg["min_row"], cfg["max_row"], **bench.synth_args(cfg, "uniform"))
+    assert row.shape[0] == cfg["nnz"] == 1_000_209      # the row counts sum to nnz exactly
     if skew:
-        row, col, val = bench.skewed_instance(cfg["seed"], U, I, int(row.shape[0]))
+        _, raw_total = capi.synth_counts(cfg["seed"], U, I, cfg["min_row"], cfg["max_row"])   # what bench.py --skew targets
+        row, col, val = bench.skewed_instance(cfg["seed"], U, I, raw_total)
     assert 8e5 < row.shape[0] < 1.2e6
     d = dict(iters=2, alpha=cfg["alpha"], feats=K, users=U, items=I, row=row, col=col, val=val)
     L, R = capi.init_factors(U, I, K)
@@ -998,6 +1000,55 @@ def test_cfg5_shape_scaled_twin_spot_checks(capi, orc):
     plan.close()
 
 
+def test_buffers_beyond_2_31_bytes_spot_checks(capi, orc, iter_mode):
+    """A factor buffer larger than 2^31 bytes (1.2e6 users x K=256 x 8 B = 2.46e9): every row offset of the user sweep,
+    of the gather of the item sweep, of the uploads / downloads and of the recommendation must be 64-bit.  Short rows keep
+    it cheap (2.4e7 entries); sampled rows -- the last users among them, whose byte offsets are the largest -- exact
+    against the oracle after one iteration."""
+    if iter_mode == "sweeps":
+        pytest.skip("covered by the other two forms")
+    U, I, K, alpha = 1_200_000, 30_000, 256, 1e-5
+    row, col, val = capi.synth_block(0xC0FFEE + 5, U, I, 15, 25, columns="uniform", target_nnz=24_000_000)
+    assert row.shape[0] == 24_000_000 and U * K * 8 > 2**31
+    L0, R0 = capi.init_factors(U, I, K)
+    plan = capi.Plan(U, I, K, alpha, row, col, val)
+    plan.upload(L0, R0)
+    plan.iterate(1)
+    L1, R1 = plan.download()
+    users = _spot_check_one_iteration(orc, U, I, K, alpha, row, col, val, L0, R0, L1, R1, 200, 30, seed=31)
+    tail = np.arange(U - 64, U)                          # byte offsets 2.457e9 .. 2.4576e9
+    sel = row >= U - 64
+    Lo, _ = orc.shard_step(0, U, I, K, row[sel], col[sel], val[sel], alpha, L0, R0, True)
+    assert np.array_equal(L1[tail], Lo[tail])
+    best = plan.recommend()
+    _check_recommend_rows(orc, best, np.concatenate([users[:4], tail[-4:]]), row, col, L1, R1, U, I)
+    plan.close()
+
+
+def test_cfg5_full_size_one_iteration_spot_checks(capi, orc, iter_mode):
+    """BASELINE.json configs[4] at its OWN size -- 1e6 x 1e6, K=256, 5e8 entries (distinct uniform columns, nnz exact):
+    both factor buffers are 2.05e9 bytes, 5 % below 2^31, the entry arrays 2e9 and 4e9 bytes.  One iteration, 200 sampled
+    users and 24 sampled items exact against the oracle.  (~25 GB of host memory, about a minute: once, not per form.)"""
+    if iter_mode != "auto":
+        pytest.skip("full size: run once")
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    cfg = bench.CONFIGS["cfg5"]
+    U, I, K, alpha = cfg["users"], cfg["items"], cfg["feats"], cfg["alpha"]
+    row, col, val = capi.synth_block(cfg["seed"], U, I, cfg["min_row"], cfg["max_row"], **bench.synth_args(cfg, "uniform"))
+    assert row.shape[0] == 500_000_000
+    L0, R0 = capi.init_factors(U, I, K)
+    plan = capi.Plan(U, I, K, alpha, row, col, val)
+    assert "KT=256" in plan.describe(), plan.describe()
+    plan.upload(L0, R0)
+    plan.iterate(1)
+    L1, R1 = plan.download()
+    plan.close()
+    _spot_check_one_iteration(orc, U, I, K, alpha, row, col, val, L0, R0, L1, R1, 200, 24, seed=55)
+
+
 def test_cfg4_full_size_spot_checks_and_properties(capi, orc):
     """BASELINE.json configs[3] -- the bench workload itself, 1e6 x 1e5, K=100, ~1e8 entries -- at FULL size:
     300 users / 40 items of the first iteration exact against the oracle, bit-reproducible, alpha = 0 is the
@@ -1008,8 +1059,8 @@ def test_cfg4_full_size_spot_checks_and_properties(capi, orc):
     import bench
     cfg = bench.CONFIGS["cfg4"]
     U, I, K, alpha = cfg["users"], cfg["items"], cfg["feats"], cfg["alpha"]
-    row, col, val = capi.synth_block(cfg["seed"], U, I, cfg["min_row"], cfg["max_row"])
-    assert row.shape[0] > 99_000_000
+    row, col, val = capi.synth_block(cfg["seed"], U, I, cfg["min_row"], cfg["max_row"], **bench.synth_args(cfg, "uniform"))
+    assert row.shape[0] == 100_000_000                  # the headline workload: distinct uniform columns, nnz exact
     L0, R0 = capi.init_factors(U, I, K)
     plan = capi.Plan(U, I, K, alpha, row, col, val)
     plan.upload(L0, R0)

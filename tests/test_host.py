@@ -148,6 +148,37 @@ def test_synthetic_generator_properties(capi):
     assert np.bincount(r3, minlength=10).tolist() == [4] * 10
 
 
+@pytest.mark.parametrize("columns", ["uniform", "zipf"])
+def test_survey_generators_exact_nnz_distinct_columns(capi, columns):
+    """SURVEY 8d's generator: m ~ U[min, max] rescaled so that the row counts sum to nnz EXACTLY, m distinct columns per
+    row -- uniform, or Zipf(1.0) item popularity (hot columns) --, sorted, ratings in {1..5}; a pure function of (seed, user):
+    any block of users equals the corresponding slice of the whole."""
+    users, items, nnz = 3000, 400, 123_457
+    row, col, val = capi.synth_block(0xC0FFEE + 4, users, items, 20, 60, columns=columns, target_nnz=nnz)
+    assert len(row) == nnz
+    counts = np.bincount(row, minlength=users)
+    raw, total = capi.synth_counts(0xC0FFEE + 4, users, items, 20, 60)
+    assert np.all(np.abs(counts - raw * (nnz / total)) <= 1.0 + 1e-9)          # within one of the scaled raw draw
+    key = row.astype(np.int64) * items + col
+    assert np.all(np.diff(key) > 0)                      # strictly (row, col)-sorted: distinct columns inside a row
+    assert col.min() >= 0 and col.max() < items and set(np.unique(val)) == {1.0, 2.0, 3.0, 4.0, 5.0}
+    per_item = np.bincount(col, minlength=items)
+    if columns == "uniform":
+        assert per_item.max() < 2.0 * per_item.mean()    # binomial around nnz / items
+    else:
+        top = np.sort(per_item)[::-1]
+        assert top[0] > 0.95 * users and top[0] > 5 * np.median(per_item)   # the hottest item is rated by nearly everybody
+        assert abs(int(np.argmax(per_item)) - 0) > 0 or True                # (its id is scattered, not necessarily 0)
+    parts = [capi.synth_block(0xC0FFEE + 4, users, items, 20, 60, u0=a, count=b, columns=columns, target_nnz=nnz)
+             for a, b in ((0, 1), (1, 1233), (1234, 1766))]
+    for i, whole in enumerate((row, col, val)):
+        assert np.array_equal(np.concatenate([p[i] for p in parts]), whole)
+    # rows longer than half of the items: the uniform draw picks the complement; every item at most once
+    r, c, _ = capi.synth_block(3, 50, 40, 25, 40, columns=columns, target_nnz=0)
+    k = r.astype(np.int64) * 40 + c
+    assert np.all(np.diff(k) > 0) and np.bincount(r, minlength=50).min() >= 25 and c.max() < 40
+
+
 def _run_cli(capi, args):
     return subprocess.run([capi.CLI_PATH] + args, capture_output=True, text=True)
 

@@ -84,19 +84,21 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-def test_two_rank_sharded_run_matches_serial(orc, tmp_path, overlap):
+@pytest.mark.parametrize("world, overlap", [(2, True), (2, False), (8, True)])
+def test_sharded_run_matches_serial(orc, tmp_path, world, overlap):
+    """world 2, and world 8 -- the size of the driver's scaling run (matFact-mpi.c's 8x1 grid for cfg4): eight ranks, user
+    blocks balanced by entries (one of them may be a single user), seed-on-root, eight-way all-reduce, gather of the lists."""
     import recommender_system_amd as rs  # noqa: F401  (registers rs.sharded)
     import importlib
     importlib.import_module("recommender_system_amd.sharded")
     d = random_instance(21, 37, 23, 6, density=0.3, iters=9, alpha=0.004, empty_rows=(4,), full_rows=(7,))
     out = str(tmp_path / "res.npz")
-    mp.spawn(_worker, args=(2, _free_port(), d, d["iters"], overlap, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), d, d["iters"], overlap, out), nprocs=world, join=True)
     got = np.load(out)
     inst = orc.Instance(**d)
     L, R = orc.init_factors(inst.users, inst.items, inst.feats)
     orc.factorize(inst, L, R)
-    # sharding re-associates the sums into R (two partial sums are added): north-star tolerance 1e-5 relative
+    # sharding re-associates the sums into R (the partial sums of the shards are added): north-star tolerance 1e-5 relative
     assert np.allclose(got["L"], L, rtol=1e-9, atol=1e-13)
     assert np.allclose(got["R"], R, rtol=1e-9, atol=1e-13)
     assert np.array_equal(got["best"], orc.recommend(inst, L, R))

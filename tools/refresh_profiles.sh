@@ -34,7 +34,7 @@ bench = json.loads([l for l in open(O + "/bench.json") if l.startswith("{")][-1]
 json.dump({"cfg4_n1": {"hbm_bytes_per_launch": (ib + ub) / 2, "item_sweep_bytes": ib, "user_sweep_bytes": ub,
                        "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
                        "kernel_source_hash": rs.capi.kernel_source_hash(),
-                       "csvs": ["profiles/r02/cfg4_n1_pmc_FETCH_SIZE.csv", "profiles/r02/cfg4_n1_pmc_WRITE_SIZE.csv"],
+                       "csvs": ["profiles/r03/cfg4_n1_pmc_FETCH_SIZE.csv", "profiles/r03/cfg4_n1_pmc_WRITE_SIZE.csv"],
                        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/refresh_profiles.sh); "
                                  "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts half of "
                                  "a 16-B/lane stream); L2->fabric requests, Infinity-Cache hits included"}},
