@@ -926,13 +926,19 @@ __global__ void __launch_bounds__(kPairThreads) sweep_pair_kernel(SweepArgs a)
 //   * an LDS read whose result hipcc cannot see pending (inline asm) is WAITED FOR INSIDE THE SAME asm STATEMENT, and its
 //     destination is an early-clobber output: no register holds a pending LDS return across statements, so no compiler
 //     copy, spill or reuse can observe one (cdna_hip_programming.md 5.7 item 1, form (i));
-//   * no LDS read is in flight while the v_fmac_f64_dpp chain executes.  Round 2 shipped, for a while, a loop that issued
-//     the read of block b+1 BEFORE the chain of block b and waited for it after: one wrong entry (all four DPP rows,
-//     both columns = one 64-byte piece of scratch) every ~1e8 blocks, only beside another kernel on a busy chip.  The ISA
-//     of that build is clean on paper (tools/micro/alt/libmatfact_hip_base.so: the pending quad v[24:27] and the quad
-//     under the chain v[6:9] are distinct, nothing reads, writes or copies the pending quad before its lgkmcnt(0), every
-//     vmcnt is where the source puts it), so the compiler is not the cause; what the hardware does there is not
-//     established.  The read-then-wait-then-chain order below was clean over 9000 lockstep iterations.
+//   * the steady state keeps the read of the next block in flight under the chain of the current one -- inside ONE
+//     statement, which ends with the wait.
+// Why: round 2 shipped, for a while, a two-register software pipeline -- the read of block b+1 issued from an asm statement
+// before the chain of block b, `s_waitcnt lgkmcnt(0)` in another asm statement at the top of the next step -- that gave one
+// wrong sum per ~1e8 blocks, only beside another kernel on a busy chip, and was blamed on the hardware (DPP beside a
+// returning LDS read).  It was a SOFTWARE bug, settled in round 3 from the builds kept in tools/micro/alt and with the
+// diagnostic build below (tools/os_diag.py): the loop's odd tail step ended in `cur = nxt;` in front of `landed(cur)`, and
+// hipcc -- for which an asm output is written when the statement ends -- emitted that copy as two v_mov_b64 of the PENDING
+// quad in front of the wait (libmatfact_hip_base.so: ds_read_b128 v[24:27] ... v_mov_b64 v[6:7], v[24:25] / v[8:9],
+// v[26:27] ... s_waitcnt lgkmcnt(0), in all three depth classes).  Whenever the read took longer than the chain in between
+// -- ~300 cycles, i.e. only on a CU whose LDS is busy -- the copy caught the register before the data.  The order that
+// "fixed" it (read after the chain) was clean only because hipcc happened to coalesce the two quads there.  Re-built this
+// round, the old order fails 93 of 1500 lockstep iterations; with one lgkmcnt(0) in front of the copy, none of 9.6e8 blocks.
 //
 // Depth classes: a CU's miss bandwidth (~29 GB/s) is shared by its resident waves in proportion to what each keeps in
 // flight, so a wave streaming the longest row must hold more than the waves of the merely long rows beside it, or it
@@ -1085,22 +1091,77 @@ __device__ __forceinline__ void ordered_sum_task(const char *src, unsigned ring_
 	if (nblk > D - 1) {   // at least one block is still to be issued
 		asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 2) : "memory");   // block 0, and the seed in front of it
 		read_seed();
-		for (; b + (D - 1) < nblk; ++b) add_block(b, EB, std::integral_constant<int, D - 2>{}, b + D - 1);
+		if constexpr (DPP) {
+			// Software-pipelined by one block, each step ONE asm statement: wait until block blk+1 has landed (blocks up to
+			// blk+D-2 are issued: at most D-3 newer ones outstanding), start its LDS read into `nxt`, run the chain of block
+			// blk out of `cur` -- complete since the previous statement ended --, issue block blk+D-1 into the slot of block
+			// blk-1, and WAIT for the read before the statement ends.  The read's latency hides under the chain, and no
+			// register is pending across statements: whatever hipcc does with `nxt` afterwards (the copy at the end of an
+			// odd run of steps below) it does to landed data.
+#define MF_CHAIN2(E)                                                                                                     \
+	"v_fmac_f64_dpp %[ax], %[cx], %[one] row_newbcast:" #E " row_mask:0xf bank_mask:0xf\n\t"                            \
+	"v_fmac_f64_dpp %[ay], %[cy], %[one] row_newbcast:" #E " row_mask:0xf bank_mask:0xf\n\t"
+			auto pstep = [&](int blk, const v2d &cur, v2d &nxt) {
+				const unsigned addr = my + slot_of(blk + 1);
+				const char *g = src + (size_t) (blk + D - 1) * 1024;
+				const unsigned m0 = __builtin_amdgcn_readfirstlane(ring_base + slot_of(blk + D - 1));
+				asm volatile("s_waitcnt vmcnt(%[w])\n\t"
+				             "ds_read_b128 %[nxt], %[addr]\n\t"
+				             MF_CHAIN2(0) MF_CHAIN2(1) MF_CHAIN2(2) MF_CHAIN2(3) MF_CHAIN2(4) MF_CHAIN2(5) MF_CHAIN2(6) MF_CHAIN2(7)
+				             MF_CHAIN2(8) MF_CHAIN2(9) MF_CHAIN2(10) MF_CHAIN2(11) MF_CHAIN2(12) MF_CHAIN2(13) MF_CHAIN2(14) MF_CHAIN2(15)
+				             "s_mov_b32 m0, %[m0]\n\t"
+				             "s_nop 0\n\t"
+				             "global_load_lds_dwordx4 %[g], off\n\t"
+				             "s_waitcnt lgkmcnt(0)"
+				             : [ax] "+v"(ax), [ay] "+v"(ay), [nxt] "=&v"(nxt)
+				             : [cx] "v"(cur.x), [cy] "v"(cur.y), [one] "v"(one), [addr] "v"(addr), [g] "v"(g), [m0] "s"(m0), [w] "n"(D - 3)
+				             : "memory");
+			};
+#undef MF_CHAIN2
+			v2d r0, r1;
+			fetch(0, r0, std::integral_constant<int, -1>{}, -1);
+			const int last = nblk - D;   // the last block whose step still has a block to issue
+			for (; b + 1 <= last; b += 2) {   // two steps per trip: the two registers swap roles
+				pstep(b, r0, r1);
+				pstep(b + 1, r1, r0);
+			}
+			if (b <= last) {
+				pstep(b, r0, r1);
+				r0 = r1;   // a copy of LANDED data
+				++b;
+			}
+			// r0 holds block b = nblk - D + 1, a full one, not yet added; every block is issued
+			{
+				const v2d v = r0;
+				MF_FMAC_BCAST(0); MF_FMAC_BCAST(1); MF_FMAC_BCAST(2); MF_FMAC_BCAST(3);
+				MF_FMAC_BCAST(4); MF_FMAC_BCAST(5); MF_FMAC_BCAST(6); MF_FMAC_BCAST(7);
+				MF_FMAC_BCAST(8); MF_FMAC_BCAST(9); MF_FMAC_BCAST(10); MF_FMAC_BCAST(11);
+				MF_FMAC_BCAST(12); MF_FMAC_BCAST(13); MF_FMAC_BCAST(14); MF_FMAC_BCAST(15);
+			}
+			++b;
+		} else
+			for (; b + (D - 1) < nblk; ++b) add_block(b, EB, std::integral_constant<int, D - 2>{}, b + D - 1);
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	if (b == 0) read_seed();
 	for (; b < nblk; ++b) add_block(b, min(EB, cnt - EB * b), std::integral_constant<int, -1>{}, -1);
 }
 #ifdef MF_OS_DIAG
-// Diagnostic build only (make csrc/libmatfact_hip_osdiag.so; tools/os_diag.py): ROUND 2'S LOOP ORDER -- the LDS read of
-// block b+1 issued before the v_fmac_f64_dpp chain of block b and waited for after it, the order that produced one wrong
-// entry per ~1e8 blocks -- with two checks after every chain, to tell which of the candidate causes it is:
+// Diagnostic builds only (make csrc/libmatfact_hip_osdiag<level>.so; tools/os_diag.py): ROUND 2'S LOOP -- the LDS read of
+// block b+1 issued before the v_fmac_f64_dpp chain of block b and waited for after it, two registers swapping roles, the
+// odd tail step ending in `cur = nxt` -- with two checks after every chain, written to tell the candidate causes apart:
 //   bit 0  the register the chain consumed differs from what the block's LDS slot holds NOW (re-read after the chain):
 //          the read returned before the transfer had landed, or returned something else than the slot's bytes;
 //   bit 1  the chain's result differs from the same 16 adds formed without DPP from the SAME register (lane e of the
 //          row fetched by ds_bpermute): the DPP chain mis-executed.
 // Neither bit set on a launch whose result is wrong: the slot itself held wrong bytes (the scratch as this wave's
 // transfers saw it).  mf_os_diag: [0] blocks checked, [1] records, then 8 words per record.
+// What the levels showed (tenth-scale Netflix shape, MF_SWEEP_LONG=3000, 1500 lockstep iterations each): level 1 (the old
+// loop, no checks) 93 wrong iterations; level 4 (the transfer issued before the chain) 131; levels 2, 3 and 5 (a check --
+// hence an `s_waitcnt lgkmcnt(0)` -- after the chain, in front of or behind the transfer) none, no record.  The checks
+// cured what they were looking for: the wait they add sits in front of the compiler's copy of the pending quad (the
+// `cur = nxt` of the tail step, see the ISA of level 1: v_mov_b64 v[8:9], v[26:27] / v[10:11], v[28:29] ahead of the
+// lgkmcnt(0)).  Cause = that copy; neither DPP nor the transfers.
 __device__ unsigned long long mf_os_diag[2 + 8 * 32];
 
 template <int D>
@@ -1128,23 +1189,38 @@ __device__ __forceinline__ void ordered_sum_task_diag(const char *src, unsigned 
 		MF_FMAC_BCAST(12); MF_FMAC_BCAST(13); MF_FMAC_BCAST(14); MF_FMAC_BCAST(15);
 	};
 	auto checked_add16 = [&](int blk, const v2d &v) {
+		// MF_OS_DIAG = 1: the old order alone (does it still fail beside this round's kernels?), 2: + the re-read check,
+		// 3: + the DPP-free recomputation (32 ds_bpermute per block: it changes the timing the most)
 		const double bx = ax, by = ay;
 		add16(v);
+		double px = ax, py = ay;
+		v2d chk = v;
+#if MF_OS_DIAG >= 3
 		// (bit 1) the same sixteen adds without DPP, from the same register
-		double px = bx, py = by;
+		px = bx;
+		py = by;
 #pragma unroll
 		for (int e = 0; e < 16; ++e) {
 			px = px + __shfl(v.x, (lane & ~15) + e);
 			py = py + __shfl(v.y, (lane & ~15) + e);
 		}
+#else
+		(void) bx;
+		(void) by;
+#endif
+#if MF_OS_DIAG >= 2
 		// (bit 0) the slot again, now that the chain is over (it is refilled one step later at the earliest)
-		v2d chk;
-		const unsigned addr = my + slot_of(blk);
-		asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(chk) : "v"(addr) : "memory");
+		{
+			const unsigned addr = my + slot_of(blk);
+			asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(chk) : "v"(addr) : "memory");
+		}
+#endif
 		int flags = 0;
 		if (__double_as_longlong(chk.x) != __double_as_longlong(v.x) || __double_as_longlong(chk.y) != __double_as_longlong(v.y)) flags |= 1;
 		if (__double_as_longlong(px) != __double_as_longlong(ax) || __double_as_longlong(py) != __double_as_longlong(ay)) flags |= 2;
+#if MF_OS_DIAG >= 2
 		if (lane == 0) atomicAdd(&mf_os_diag[0], 1ull);
+#endif
 		if (flags) {
 			const unsigned long long slot = atomicAdd(&mf_os_diag[1], 1ull);
 			if (slot < 32) {
@@ -1186,8 +1262,47 @@ __device__ __forceinline__ void ordered_sum_task_diag(const char *src, unsigned 
 			landed(have);
 			asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 3) : "memory");
 			read_block(blk + 1, want);   // in flight under the chain below
+#if MF_OS_DIAG == 4
+			issue(blk + D - 1);          // 4: the transfer issued BEFORE the chain instead of after it
+			add16(have);
+#elif MF_OS_DIAG == 5
+			// 5: the failing sequence untouched -- read, chain, transfer -- and the checks only AFTER the transfer is out
+			const double bx = ax, by = ay;
+			add16(have);
+			issue(blk + D - 1);
+			{
+				double px = bx, py = by;
+#pragma unroll
+				for (int e = 0; e < 16; ++e) {
+					px = px + __shfl(have.x, (lane & ~15) + e);
+					py = py + __shfl(have.y, (lane & ~15) + e);
+				}
+				v2d chk;
+				const unsigned addr = my + slot_of(blk);
+				asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(chk) : "v"(addr) : "memory");
+				int flags = 0;
+				if (__double_as_longlong(chk.x) != __double_as_longlong(have.x) || __double_as_longlong(chk.y) != __double_as_longlong(have.y)) flags |= 1;
+				if (__double_as_longlong(px) != __double_as_longlong(ax) || __double_as_longlong(py) != __double_as_longlong(ay)) flags |= 2;
+				if (lane == 0) atomicAdd(&mf_os_diag[0], 1ull);
+				if (flags) {
+					const unsigned long long slot = atomicAdd(&mf_os_diag[1], 1ull);
+					if (slot < 32) {
+						unsigned long long *r = mf_os_diag + 2 + 8 * slot;
+						r[0] = (unsigned long long) task;
+						r[1] = (unsigned long long) blk | ((unsigned long long) nblk << 32);
+						r[2] = (unsigned long long) lane | ((unsigned long long) flags << 32) | ((unsigned long long) D << 40);
+						r[3] = (unsigned long long) __double_as_longlong(have.x);
+						r[4] = (unsigned long long) __double_as_longlong(chk.x);
+						r[5] = (unsigned long long) __double_as_longlong(ax);
+						r[6] = (unsigned long long) __double_as_longlong(px);
+						r[7] = (unsigned long long) __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+					}
+				}
+			}
+#else
 			checked_add16(blk, have);
 			issue(blk + D - 1);
+#endif
 		};
 		for (; b + D < nblk; b += 2) {
 			step(b, cur, nxt);
