@@ -21,16 +21,16 @@ def _need_gpu(capi):
         pytest.fail("GPU tests need an MI355X; mf_backend_device_count() = %d" % capi.device_count())
 
 
-@pytest.fixture(params=["auto", "sweeps", "sweeps-plain"], autouse=True)
+@pytest.fixture(params=["auto", "sweeps", "sweeps-db"], autouse=True)
 def iter_mode(request, monkeypatch):
     """Every test runs three times: with the iteration form the plan picks by itself (errors + streams for cache-resident
-    factors, mf_stream.hip.h; the double-buffered sweep for launches of few rows), with the two sweeps forced (double-buffered
-    where the plan chooses that, i.e. at every test's size) and with the two sweeps in their single-buffered form (the kernel
-    large launches run: MF_SWEEP_DB=0) -- so that all of them stay pinned on the oracle."""
+    factors, mf_stream.hip.h), with the two sweeps forced (the single-buffered single-wave kernel, or whatever the plan's
+    schedule puts beside it) and with the two sweeps in the intra-wave double-buffered form (MF_SWEEP_DB=1: a kernel the plan
+    never picks by itself, kept selectable) -- so that all of them stay pinned on the oracle."""
     if request.param != "auto":
         monkeypatch.setenv("MF_ITER_MODE", "sweeps")
-    if request.param == "sweeps-plain":
-        monkeypatch.setenv("MF_SWEEP_DB", "0")
+    if request.param == "sweeps-db":
+        monkeypatch.setenv("MF_SWEEP_DB", "1")
     return request.param
 
 
@@ -232,6 +232,7 @@ def test_wave_pair_sweep_bit_exact(capi, orc, k, nch, monkeypatch):
     val = rng.integers(1, 6, len(row)).astype(np.float64)
     monkeypatch.setenv("MF_SWEEP_PAIR", "1")
     monkeypatch.setenv("MF_ITER_MODE", "sweeps")
+    monkeypatch.delenv("MF_SWEEP_DB", raising=False)    # (the fixture's double-buffered form would take precedence)
     if nch:
         monkeypatch.setenv("MF_SWEEP_NCH", nch)
     alpha = 1e-3 / k
@@ -275,7 +276,7 @@ def test_wave_pair_rule_and_extreme_rows_beside_it(capi, orc, monkeypatch):
     row, col = np.concatenate(rows), np.concatenate(cols)
     val = rng.integers(1, 6, len(row)).astype(np.float64)
     monkeypatch.setenv("MF_ITER_MODE", "sweeps")
-    monkeypatch.delenv("MF_SWEEP_DB", raising=False)
+    monkeypatch.delenv("MF_SWEEP_DB", raising=False)   # the plan's own choice (the fixture may have forced another form)
     d = dict(iters=3, alpha=2e-6, feats=K, users=U, items=I, row=row, col=col, val=val)
     plan = capi.Plan(U, I, K, d["alpha"], row, col, val)
     desc = plan.describe()
@@ -288,6 +289,28 @@ def test_wave_pair_rule_and_extreme_rows_beside_it(capi, orc, monkeypatch):
     Lo, Ro = L0.copy(), R0.copy()
     orc.factorize(orc.Instance(**d), Lo, Ro)
     assert np.array_equal(L, Lo) and np.array_equal(R, Ro)
+
+
+def test_switches_are_read_once_per_plan_and_experiments_are_not_in_the_shipped_library(capi, monkeypatch):
+    """csrc/mf_config.hip.h: a plan's behaviour is fixed when it is created (a switch set afterwards changes nothing),
+    mf_plan_describe names every documented switch that differs from its default, and the shipped library ignores the
+    experiment-only ones (they exist in the -DMF_EXPERIMENTS build only)."""
+    d = random_instance(3, 120, 90, 100, density=0.3)
+    for k in ("MF_ITER_MODE", "MF_SWEEP_DB", "MF_SWEEP_NCH", "MF_SWEEP_SEG", "MF_SWEEP_PNCH", "MF_ES_NCH", "MF_SWEEP_FEW"):
+        monkeypatch.delenv(k, raising=False)
+    plain = capi.Plan(120, 90, 100, 0.01, d["row"], d["col"], d["val"])
+    assert "config{" not in plain.describe(), plain.describe()
+    monkeypatch.setenv("MF_SWEEP_NCH", "7")             # documented: honoured, by the NEXT plan only
+    assert "config{" not in plain.describe() and " nch=16 " in plain.describe()
+    later = capi.Plan(120, 90, 100, 0.01, d["row"], d["col"], d["val"])
+    assert "config{MF_SWEEP_NCH=7}" in later.describe() and " nch=7 " in later.describe(), later.describe()
+    monkeypatch.delenv("MF_SWEEP_NCH")
+    for k, v in (("MF_SWEEP_SEG", "32"), ("MF_SWEEP_PNCH", "8"), ("MF_ES_NCH", "8"), ("MF_SWEEP_FEW", "1"), ("MF_SWEEP_PF", "0")):
+        monkeypatch.setenv(k, v)                        # experiments: not compiled into the shipped library
+    exp = capi.Plan(120, 90, 100, 0.01, d["row"], d["col"], d["val"])
+    assert exp.describe() == plain.describe(), (exp.describe(), plain.describe())
+    for p in (plain, later, exp):
+        p.close()
 
 
 def test_dispatch_order_of_a_large_skewed_sweep(capi, orc):
