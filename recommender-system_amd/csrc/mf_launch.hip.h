@@ -40,7 +40,7 @@ bool sweep_is_dma(const mf_config &cfg, int K)
 int choose_sweep(mf_plan *p)
 {
 	const int K = p->K;
-	p->sweep = SweepVariant{nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	p->sweep = SweepVariant{nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	const bool allow_dma = !p->cfg.sweep_reg;   // MF_SWEEP_IMPL=dma (default) | reg: register-staged form only
 	if (allow_dma)
 		for (const auto &v : kDma)
@@ -99,6 +99,8 @@ int choose_sweep(mf_plan *p)
 		while (npr > 1 && head + 2 * (size_t) npr * row_bytes > kLdsPerCu / 2) --npr;
 		p->nch_pair = npr;
 		p->lds_bytes_pair = head + 2 * (size_t) npr * row_bytes;
+		p->pair_loaders = p->cfg.pair_loaders == 2 && p->sweep.pair2 ? 2 : 1;
+		if (p->pair_loaders == 2) p->sweep.pair = p->sweep.pair2;
 		MF_HIP(raise_lds_limit((const void *) p->sweep.pair, p->lds_bytes_pair));
 	}
 	// double-buffered form (few rows per CU: the wave hides its own gather): two tiles of nch_db rows
@@ -183,7 +185,7 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 	constexpr int kPfRows = 262144;
 	const SweepFn single = p->sweep.pf && p->n_short[kind] <= kPfRows && a.nrows <= kPfRows ? p->sweep.pf : p->sweep.fn;
 	const SweepFn fn = coop ? p->sweep.coop : db ? p->sweep.db : pair ? p->sweep.pair : single;
-	const int block = coop ? mf::kCoopWaves * mf::kWave : pair ? mf::kPairThreads : mf::kWave;
+	const int block = coop ? mf::kCoopWaves * mf::kWave : pair ? (p->pair_loaders + 1) * mf::kWave : mf::kWave;
 	const int grid = std::min(a.nrows, 1 << 20);
 	TimedLaunch t{};
 	if (p->timing) {
@@ -266,7 +268,7 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 			                       dim3(mf::kCoopWaves * mf::kWave), args, p->lds_bytes_coop, p->stream));
 		} else if (a.nrows > 0 && pair) {
 			a.nch = p->nch_pair;
-			MF_HIP(hipLaunchKernel((const void *) p->sweep.pair, dim3(std::min(a.nrows, 1 << 20)), dim3(mf::kPairThreads), args,
+			MF_HIP(hipLaunchKernel((const void *) p->sweep.pair, dim3(std::min(a.nrows, 1 << 20)), dim3((p->pair_loaders + 1) * mf::kWave), args,
 			                       p->lds_bytes_pair, p->stream));
 		} else if (a.nrows > 0 && db) {
 			a.nch = p->nch_db;

@@ -45,19 +45,20 @@ struct SweepVariant {
 	SweepFn db;     // intra-wave double-buffered form for launches of few rows (all DMA variants)
 	SweepFn pf;     // accumulate form with the LDS reads of phases A / B kept in flight (compile-time-K DMA variants)
 	SweepFn pair;   // wave-pair form (loader + compute) for launches that end on long rows (64 <= K <= 128, compile-time K)
+	SweepFn pair2;  // ... with two loader waves
 };
 
 template <int KT, int KP>
 constexpr SweepVariant variant()
 {
-	return SweepVariant{mf::sweep_kernel<KT, KP>, KT, KP, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	return SweepVariant{mf::sweep_kernel<KT, KP>, KT, KP, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 }
 
-template <int KT>
+template <int KT, int NL>
 constexpr SweepFn pair_fn()
 {
 	if constexpr (mf::DmaGeom<KT>::kPasses == 1 && (mf::DmaGeom<KT>::kPieces | 1) > 32)
-		return mf::sweep_pair_kernel<KT>;
+		return mf::sweep_pair_kernel<KT, NL>;
 	else
 		return nullptr;
 }
@@ -70,7 +71,13 @@ constexpr SweepVariant dma_variant()
 	                    mf::sweep_dma_kernel<KT, mf::DmaGeom<KT>::kPasses, mf::kSweepProducts>,
 	                    mf::sweep_dma_kernel<KT, mf::DmaGeom<KT>::kPasses, mf::kSweepErrors>,
 	                    mf::sweep_db_kernel<KT, mf::DmaGeom<KT>::kPasses>,
-	                    mf::sweep_dma_kernel<KT, mf::DmaGeom<KT>::kPasses, mf::kSweepAccumulate, 8>, pair_fn<KT>()};
+	                    mf::sweep_dma_kernel<KT, mf::DmaGeom<KT>::kPasses, mf::kSweepAccumulate, 8>, pair_fn<KT, 1>(),
+#ifdef MF_EXPERIMENTS
+	                    pair_fn<KT, 2>()   // two loader waves: measured within noise of one (the compute wave is the bound)
+#else
+	                    nullptr
+#endif
+	};
 }
 
 // run-time even K <= 128 * NPASS through the LDS-DMA kernel (row_bytes / xs_bytes filled in per plan)
@@ -79,7 +86,7 @@ constexpr SweepVariant dma_generic_variant()
 {
 	return SweepVariant{mf::sweep_dma_kernel<0, NPASS>, 0, NPASS, 1, 0, 0, nullptr,
 	                    mf::sweep_dma_kernel<0, NPASS, mf::kSweepProducts>, mf::sweep_dma_kernel<0, NPASS, mf::kSweepErrors>,
-	                    mf::sweep_db_kernel<0, NPASS>, nullptr, nullptr};
+	                    mf::sweep_db_kernel<0, NPASS>, nullptr, nullptr, nullptr};
 }
 
 // K-specialised instances for the K of the bundled samples and of the BASELINE configs, then generic ones.
@@ -169,6 +176,7 @@ struct mf_plan {
 	bool use_db[2] = {false, false};   // the sweep's single-wave launch takes the double-buffered form (plan_row_schedule)
 	bool use_pair[2] = {false, false}; // ... or the wave-pair form
 	int nch_pair = 0;
+	int pair_loaders = 1;   // loader waves of the wave-pair form
 	size_t lds_bytes_pair = 0;
 	// mid-length rows of a skewed sweep (below the extreme threshold, far above the mean): their own launch of the
 	// double-buffered form with a LARGE chunk on a second side stream -- a wave that keeps 48 rows in flight gets a

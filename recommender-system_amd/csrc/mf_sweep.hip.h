@@ -767,6 +767,9 @@ __device__ __forceinline__ double phase_a_dot_ahead(const double2 *t2, const dou
 			t[q % PF] = t2[q + PF];
 			x[q % PF] = xs[q + PF];
 		}
+		// (pinning the multiplies of step q+1 between the adds of steps q-1 and q with register operands on this statement
+		// was measured SLOWER -- a lone 5993-entry row 0.327 -> 0.347 ms --: hipcc's own placement, each multiply in front
+		// of its add, stays)
 		asm volatile("" ::: "memory");
 		dot = dot + px;
 		dot = dot + py;
@@ -776,10 +779,11 @@ __device__ __forceinline__ double phase_a_dot_ahead(const double2 *t2, const dou
 	return dot;
 }
 
-constexpr int kPairThreads = 2 * kWave;
-
-template <int KT>
-__global__ void __launch_bounds__(kPairThreads) sweep_pair_kernel(SweepArgs a)
+// NL loader waves + one compute wave.  NL = 2: the two loaders issue alternate groups of four rows of a chunk, so the
+// ~90 cycles per gathered row -- what a pair is bound by -- are paid in parallel and the walk becomes bound by the compute
+// wave (phases A + B).
+template <int KT, int NL = 1>
+__global__ void __launch_bounds__((NL + 1) * kWave) sweep_pair_kernel(SweepArgs a)
 {
 	using G = DmaGeom<KT>;
 	static_assert(G::kPasses == 1 && (G::kPieces | 1) > 32, "one LDS-DMA instruction per gathered row");
@@ -802,8 +806,8 @@ __global__ void __launch_bounds__(kPairThreads) sweep_pair_kernel(SweepArgs a)
 		// long rows are what the launch ends on: both of their waves run at raised priority (instruction issue is
 		// arbitrated by priority, then age) beside the waves of short rows on the same SIMDs
 		const bool long_row = a.prio_len > 0 && end - beg >= a.prio_len;
-		if (wave == 0) {
-			// ---------------- loader: chunk c -> tile c & 1, then "landed" = barrier c
+		if (wave < NL) {
+			// ---------------- loader(s): chunk c -> tile c & 1, then "landed" = barrier c
 			if (long_row)
 				__builtin_amdgcn_s_setprio(3);
 			else
@@ -820,8 +824,8 @@ __global__ void __launch_bounds__(kPairThreads) sweep_pair_kernel(SweepArgs a)
 				const unsigned long long rowaddr = ybase + (unsigned long long) (unsigned) my_idx * ybytes;
 				const int alo = (int) (unsigned) rowaddr, ahi = (int) (unsigned) (rowaddr >> 32);
 				const unsigned tb = tile0_lds + (unsigned) (buf * tile_bytes);
-				int n = 0;
-				for (; n + 4 <= cnt; n += 4) {
+				int n = 4 * wave;   // loader w takes the groups of four rows w, w + NL, ...
+				for (; n + 4 <= cnt; n += 4 * NL) {
 					unsigned long long b[4];
 #pragma unroll
 					for (int u = 0; u < 4; ++u)
@@ -836,13 +840,13 @@ __global__ void __launch_bounds__(kPairThreads) sweep_pair_kernel(SweepArgs a)
 							             : "memory");
 					}
 				}
-				for (; n < cnt; ++n) {
-					const unsigned long long b = ((unsigned long long) (unsigned) __builtin_amdgcn_readlane(ahi, n) << 32) |
-					                             (unsigned long long) (unsigned) __builtin_amdgcn_readlane(alo, n);
+				for (int m = n; m < min(n + 4, cnt); ++m) {   // the last, partial group of four belongs to the loader it falls to
+					const unsigned long long b = ((unsigned long long) (unsigned) __builtin_amdgcn_readlane(ahi, m) << 32) |
+					                             (unsigned long long) (unsigned) __builtin_amdgcn_readlane(alo, m);
 					if (lane < P)
 						asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0"
 						             :
-						             : "s"(b), "s"(tb + (unsigned) (n * S)), "v"(voff)
+						             : "s"(b), "s"(tb + (unsigned) (m * S)), "v"(voff)
 						             : "memory");
 				}
 				// landed (this also retires the index load of the next chunk, issued in front of the transfers)
