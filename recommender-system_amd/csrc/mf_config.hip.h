@@ -33,6 +33,7 @@ struct mf_config {
 	bool rec_exact = false;           // MF_RECOMMEND_IMPL=exact: the exact recommendation kernel only
 	bool rec_ares = true;             // MF_RECOMMEND_ARES=0: no LDS-resident L image in the MFMA pass
 	bool rec_bdma = true;             // MF_RECOMMEND_BDMA=0: R chunks staged through registers
+	int rec_split = -1;               // MF_RECOMMEND_SPLIT=0|n: item split of small recommendations off / n splits (-1: rule)
 	bool build_host = false;          // MF_BUILD=host: CSR/CSC bucketed on the host
 	bool os_dpp = true;               // MF_OS_DPP=0: ordered sums by plain v_add_f64 (no DPP broadcast)
 	bool multi_force = false;         // MF_MULTI_FORCE=1: sharded path even with one shard
@@ -88,6 +89,7 @@ struct mf_config {
 		c.rec_exact = eq(getenv("MF_RECOMMEND_IMPL"), "exact");
 		c.rec_ares = !is0(getenv("MF_RECOMMEND_ARES"));
 		c.rec_bdma = !is0(getenv("MF_RECOMMEND_BDMA"));
+		if ((v = getenv("MF_RECOMMEND_SPLIT"))) c.rec_split = atoi(v);
 		c.build_host = eq(getenv("MF_BUILD"), "host");
 		c.os_dpp = !is0(getenv("MF_OS_DPP"));
 		c.multi_force = eq(getenv("MF_MULTI_FORCE"), "1");
@@ -140,6 +142,7 @@ struct mf_config {
 		if (rec_exact) add("MF_RECOMMEND_IMPL", "exact");
 		if (!rec_ares) add("MF_RECOMMEND_ARES", "0");
 		if (!rec_bdma) add("MF_RECOMMEND_BDMA", "0");
+		if (rec_split >= 0) add("MF_RECOMMEND_SPLIT", std::to_string(rec_split));
 		if (build_host) add("MF_BUILD", "host");
 		if (!os_dpp) add("MF_OS_DPP", "0");
 		if (multi_force) add("MF_MULTI_FORCE", "1");

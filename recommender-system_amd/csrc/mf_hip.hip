@@ -220,6 +220,7 @@ void mf_plan_destroy(mf_plan *p)
 	(void) hipFree(p->cand_dev);
 	(void) hipFree(p->cand_pack);
 	(void) hipFree(p->filt_dev);
+	(void) hipFree(p->part_dev);
 	if (!p->r_external) {
 		(void) hipFree(p->Rbuf[0]);
 		(void) hipFree(p->Rbuf[1]);
@@ -506,8 +507,37 @@ static int launch_recommend_pass1(mf_plan *p, mf_filter *filt)
 		          : (vec ? mf::recommend_mfma_kernel<true, 32, false> : mf::recommend_mfma_kernel<false, 32, false>);
 	const size_t lds = mf::rec_mfma_lds(p->K, kc, ares);
 	MF_HIP(raise_lds_limit((const void *) fn, lds));
-	hipLaunchKernelGGL(fn, dim3((p->uc + mf::kMU - 1) / mf::kMU), dim3(mf::kMThreads), lds, p->stream, m);
+	// Small problems: a workgroup owns 128 users and ALL items, so few users leave most of the chip idle (cfg3: 48
+	// workgroups on 256 CUs).  The items are then split over gridDim.y -- whole 128-item tiles, about two workgroups per
+	// CU in all -- and the per-split top-2 reports merged and certified by merge_splits_kernel.
+	const int ublocks = (p->uc + mf::kMU - 1) / mf::kMU, tiles = (p->items + mf::kMI - 1) / mf::kMI;
+	int nsplit = 1;
+	if (p->cfg.rec_split != 0 && ublocks < 192 && tiles >= 2) {
+		nsplit = p->cfg.rec_split > 0 ? p->cfg.rec_split : (512 + ublocks - 1) / ublocks;
+		nsplit = std::max(1, std::min(nsplit, tiles));
+	}
+	m.split_items = 0;
+	m.part = nullptr;
+	if (nsplit > 1) {
+		const int tiles_per = (tiles + nsplit - 1) / nsplit;
+		nsplit = (tiles + tiles_per - 1) / tiles_per;
+		m.split_items = tiles_per * mf::kMI;
+		if (p->part_cap < nsplit) {
+			(void) hipFree(p->part_dev);
+			p->part_dev = nullptr;
+			p->part_cap = 0;
+			const int rc = dev_alloc(&p->part_dev, (size_t) nsplit * (size_t) p->uc);
+			if (rc != MF_OK) return rc;
+			p->part_cap = nsplit;
+		}
+		m.part = p->part_dev;
+	}
+	hipLaunchKernelGGL(fn, dim3(ublocks, nsplit), dim3(mf::kMThreads), lds, p->stream, m);
 	MF_HIP(hipGetLastError());
+	if (nsplit > 1) {
+		hipLaunchKernelGGL(mf::merge_splits_kernel, dim3((p->uc + 255) / 256), dim3(256), 0, p->stream, m, nsplit);
+		MF_HIP(hipGetLastError());
+	}
 	return MF_OK;
 }
 
@@ -544,17 +574,18 @@ int mf_plan_recommend(mf_plan *p, int32_t *best)
 			const int rc1 = launch_recommend_pass1(p, nullptr);
 			if (rc1 != MF_OK) return rc1;
 		}
+		// the list travels with the count of uncertified users: one synchronisation when nobody needs the exact pass
+		// (the common case: 0 of 1e6 users at cfg4), a second copy of the list only behind an exact pass
 		int cnt = 0;
 		MF_HIP(hipMemcpyAsync(&cnt, p->ucount, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+		MF_HIP(hipMemcpyAsync(best, p->best_dev, (size_t) p->uc * sizeof(int), hipMemcpyDeviceToHost, p->stream));
 		MF_HIP(hipStreamSynchronize(p->stream));
 		p->last_uncertain = cnt;
-		if (cnt > 0) {
-			ex.users = cnt;
-			ex.ulist = p->ulist;
-			hipLaunchKernelGGL(mf::recommend_kernel, dim3((cnt + mf::kRT - 1) / mf::kRT), dim3(256), 0, p->stream,
-			                   ex);
-			MF_HIP(hipGetLastError());
-		}
+		if (cnt == 0) return MF_OK;
+		ex.users = cnt;
+		ex.ulist = p->ulist;
+		hipLaunchKernelGGL(mf::recommend_kernel, dim3((cnt + mf::kRT - 1) / mf::kRT), dim3(256), 0, p->stream, ex);
+		MF_HIP(hipGetLastError());
 	}
 	MF_HIP(hipMemcpyAsync(best, p->best_dev, (size_t) p->uc * sizeof(int), hipMemcpyDeviceToHost, p->stream));
 	MF_HIP(hipStreamSynchronize(p->stream));

@@ -157,6 +157,8 @@ struct mf_plan {
 	mf_candidate *cand_dev = nullptr;   // recommend_scored output, allocated on first use
 	mf_candidate *cand_pack = nullptr;  // the listed users' records in list order (recommend_scored_users)
 	mf_filter *filt_dev = nullptr;      // recommend_filter output, allocated on first use
+	mf_filter *part_dev = nullptr;      // per-split reports of a small recommendation (nsplit x users), allocated on first use
+	int part_cap = 0;
 	int cur = 0;            // generation index of the current factors
 	bool have_factors = false;
 	int *best_dev = nullptr;

@@ -226,6 +226,10 @@ struct RecMfmaArgs {
 	int *__restrict__ ulist;                   // out: users that need the exact pass
 	int *__restrict__ ucount;
 	mf_filter *__restrict__ filt;              // optional: report (best, second, arg, non-finite) instead of certifying
+	// item split (small problems): blockIdx.y = split s scores items [s * split_items, (s + 1) * split_items) only and
+	// writes its report to part[s * users + user]; merge_splits_kernel certifies over the splits afterwards
+	int split_items;                           // 0: no split (gridDim.y == 1), else a multiple of 128
+	mf_filter *__restrict__ part;
 };
 
 __global__ void __launch_bounds__(kWave) row_norm_kernel(const double *__restrict__ X, int rows, int K, int ld,
@@ -431,12 +435,15 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 		if (lane == 0) lmax_bits[wave] = b;
 	}
 
+	// the items this workgroup scores: all of them, or split blockIdx.y of a small problem
+	const int j_first = a.split_items ? (int) blockIdx.y * a.split_items : 0;
+	const int j_end = a.split_items ? min(a.items, j_first + a.split_items) : a.items;
 	int buf = 0;
 	if (BDMA) {
-		dma_chunk(0, 0, 0);
+		dma_chunk(j_first, 0, 0);
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	} else {
-		fetch(0, 0);
+		fetch(j_first, 0);
 		stage(0);
 	}
 	__syncthreads();
@@ -446,7 +453,7 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 		const double bound = __longlong_as_double((long long) lb) * __longlong_as_double((long long) *a.rnorm_max_bits);
 		all_finite = bound <= 1e300;   // false for NaN
 	}
-	for (int j0 = 0; j0 < a.items; j0 += kMI) {
+	for (int j0 = j_first; j0 < j_end; j0 += kMI) {
 		mf_d4 acc[2][4];
 #pragma unroll
 		for (int tu = 0; tu < 2; ++tu)
@@ -456,7 +463,7 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 		// rated-item mask of this tile: bit jj of word w = item j0 + 64*w + jj is rated or beyond the last item.
 		// Written at the START of the tile into the parity's copy: the chunk barriers below publish it before the
 		// arg-max step reads it, and the other parity is not rewritten before every wave has passed them again.
-		const int par = (j0 / kMI) & 1;
+		const int par = ((j0 - j_first) / kMI) & 1;
 		if (tid < kMU) {
 			unsigned long long m0 = 0, m1 = 0;
 			while (nextcol < j0 + kMI) {
@@ -469,7 +476,7 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 				nextcol = nextcol2;
 				nextcol2 = cur + 1 < cend ? a.csr_idx[cur + 1] : INT32_MAX;
 			}
-			const int left = a.items - j0;   // > 0
+			const int left = j_end - j0;   // > 0
 			if (left < 64) {
 				m0 |= ~0ull << left;
 				m1 = ~0ull;
@@ -482,15 +489,15 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 
 		for (int kc = 0; kc < K; kc += KC) {
 			// next chunk (of this tile, or the first of the next tile): global loads fly behind the MFMAs
-			const bool more = kc + KC < K || j0 + kMI < a.items;
+			const bool more = kc + KC < K || j0 + kMI < j_end;
 			if (BDMA) {   // straight into the OTHER buffer (last read one chunk ago; every wave passed a barrier since)
 				if (kc + KC < K)
 					dma_chunk(j0, kc + KC, buf ^ 1);
-				else if (j0 + kMI < a.items)
+				else if (j0 + kMI < j_end)
 					dma_chunk(j0 + kMI, 0, buf ^ 1);
 			} else if (kc + KC < K)
 				fetch(j0, kc + KC);
-			else if (j0 + kMI < a.items)
+			else if (j0 + kMI < j_end)
 				fetch(j0 + kMI, 0);
 			const double *Ab = reinterpret_cast<const double *>(rec_lds + (ARES ? (kc / KC) : buf) * kChunkD2);
 			const double *Bb = reinterpret_cast<const double *>(Bs0 + buf * kChunkD2);
@@ -584,6 +591,10 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 		const Top2 o{red_b1[tid][1], red_b2[tid][1], red_i1[tid][1]};
 		top2_merge(t, o);
 		const int bd = red_bad[tid][0] | red_bad[tid][1];
+		if (a.split_items) {   // certification over the splits: merge_splits_kernel
+			a.part[(size_t) blockIdx.y * a.users + i0 + tid] = mf_filter{t.b1, t.b2, t.i1, bd};
+			return;
+		}
 		if (a.filt) {   // certification is the caller's, over several item blocks
 			a.filt[i0 + tid] = mf_filter{t.b1, t.b2, t.i1, bd};
 			return;
@@ -597,6 +608,35 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 			a.best[i0 + tid] = -2;
 			a.ulist[atomicAdd(a.ucount, 1)] = i0 + tid;
 		}
+	}
+}
+
+// Item split of a SMALL recommendation (few user blocks: cfg3 has 48 for 256 CUs): every split reported its top-2 per
+// user; merged here in item order (top2_merge: the winner's runner-up is the larger of its own and the other splits'
+// bests), then certified or reported exactly as the unsplit kernel does.
+__global__ void __launch_bounds__(256) merge_splits_kernel(RecMfmaArgs a, int nsplit)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= a.users) return;
+	Top2 t{-__builtin_inf(), -__builtin_inf(), -1};
+	int bd = 0;
+	for (int s = 0; s < nsplit; ++s) {
+		const mf_filter f = a.part[(size_t) s * a.users + i];
+		top2_merge(t, Top2{f.best, f.second, f.arg});
+		bd |= f.nonfinite;
+	}
+	if (a.filt) {
+		a.filt[i] = mf_filter{t.b1, t.b2, t.i1, bd};
+		return;
+	}
+	const double rmax = __longlong_as_double((long long) *a.rnorm_max_bits);
+	const double thr = a.thr_scale * a.lnorm[i] * rmax + 1e-300;
+	const bool certain = !bd && (t.i1 < 0 || (t.b1 - t.b2) > thr);
+	if (certain) {
+		a.best[i] = t.i1;
+	} else {
+		a.best[i] = -2;
+		a.ulist[atomicAdd(a.ucount, 1)] = i;
 	}
 }
 

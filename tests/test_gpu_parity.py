@@ -477,6 +477,44 @@ def test_recommend_every_chunk_depth_and_staging_form(capi, orc, k, monkeypatch)
         assert np.array_equal(best, want), (k, bdma)
 
 
+@pytest.mark.parametrize("split", ["0", "2", "3", "7", None])
+def test_recommend_item_split_of_small_problems(capi, orc, split, monkeypatch):
+    """A small recommendation (few 128-user blocks) splits the ITEMS over gridDim.y and merges the per-split top-2 reports
+    (merge_splits_kernel): every split count -- none, the plan's own choice, counts that do not divide the tiles --
+    against the oracle, with planted duplicates (certified only by the exact pass, lowest index wins), a fully rated user,
+    items that are not a multiple of the tile and a user whose unrated items all lie in the last split."""
+    u, i, k = 300, 1000, 100
+    rng = np.random.default_rng(4100)
+    L = rng.standard_normal((u, k))
+    R = rng.standard_normal((i, k))
+    R[i - 1] = R[0]
+    R[700] = R[130]
+    L[20] = 3.0 * R[130]                                 # user 20's top score is the duplicate pair 130 / 700: lowest index wins
+    d = random_instance(4101, u, i, k, density=0.15, full_rows=(7,))
+    mask = np.ones((u, i), bool)
+    mask[11, :] = True
+    mask[11, 990:] = False                               # user 11: only items 990.. are unrated
+    keep = ~((d["row"] == 11))
+    row = np.concatenate([d["row"][keep], np.full(990, 11, np.int32)])
+    col = np.concatenate([d["col"][keep], np.arange(990, dtype=np.int32)])
+    order = np.lexsort((col, row))
+    row, col = np.ascontiguousarray(row[order]), np.ascontiguousarray(col[order])
+    val = np.ones(len(row))
+    if split is None:
+        monkeypatch.delenv("MF_RECOMMEND_SPLIT", raising=False)
+    else:
+        monkeypatch.setenv("MF_RECOMMEND_SPLIT", split)
+    inst = orc.Instance(1, 0.0, k, u, i, row, col, val)
+    want = orc.recommend(inst, L, R)
+    plan = capi.Plan(u, i, k, 0.0, row, col, val)
+    plan.upload(L, R)
+    best = plan.recommend()
+    assert plan.recommend_info() >= 0                    # the matrix-core form ran (users whose top is a duplicate pair: exact pass)
+    plan.close()
+    assert np.array_equal(best, want), (split, np.where(best != want)[0][:8])
+    assert want[7] == -1 and want[11] >= 990 and (want[20] == 130 or 130 in col[row == 20])
+
+
 def test_mfma_certification_sends_near_ties_to_the_exact_pass(capi, orc):
     """Scores closer than the rounding bound must not be decided by the matrix cores."""
     u, i, k = 200, 300, 64
