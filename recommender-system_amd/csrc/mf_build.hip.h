@@ -397,16 +397,19 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 {
 	for (int u = 0; u < p->uc; ++u) p->max_row_len[1] = std::max(p->max_row_len[1], rptr[(size_t) u + 1] - rptr[u]);
 	for (int j = 0; j < p->items; ++j) p->max_row_len[0] = std::max(p->max_row_len[0], cptr[(size_t) j + 1] - cptr[j]);
-	// ---- long / short row lists.  A row is "long" when its serial walk (~0.075 us per entry at 16-entry
-	// chunks) would exceed roughly a quarter of the bandwidth time of the whole sweep (nnz * 8K bytes at
-	// ~7 TB/s): len > 4e-6 * nnz * K, and never below 128 entries.  cfg4 has none; a power-law instance a few.
+	// ---- long / short row lists.  A row is "long" when its serial walk would exceed a good part of the bandwidth time
+	// of the whole sweep (nnz * 8K bytes at ~7 TB/s): len > 4e-6 (6e-6) * nnz * K, and never below 128 entries.  cfg4
+	// has none; a power-law instance a few.
 	const mf_config &cfg = p->cfg;
 	if (p->sweep.prod && cfg.skew) {   // MF_SWEEP_SKEW=0 disables the split
 		const size_t per_entry = 2 * (size_t) mf::kCoopProducers * (size_t) p->sweep.row_bytes;
 		const size_t head = (size_t) p->sweep.xs_bytes;
 		int nl = (int) std::min<size_t>(32, (kLdsPerCu - 4096 - head) / per_entry);
 		if (const int v = cfg.sweep_nch; v >= 1 && head + (size_t) v * per_entry <= kLdsPerCu) nl = v;
-		double thr = 4e-6 * (double) p->nnz * (double) p->K;
+		// (6e-6 where the accumulate form with the pipelined phases exists: its lone wave walks 0.13 us per entry at K=100
+		// instead of 0.17, so fewer rows need the scratch round trip -- Netflix shape 21.05 -> 19.68 ms at 40000 instead of
+		// 26800 entries, cfg4-Zipf 34.5 -> 33.9; round 2's 4e-6 otherwise)
+		double thr = (p->sweep.pf ? 6e-6 : 4e-6) * (double) p->nnz * (double) p->K;
 		if (cfg.sweep_long_set) thr = cfg.sweep_long;
 		const int t_long = std::max(128, (int) std::min(thr, 2e9));
 		// estimated bandwidth time of one sweep; below ~50 us the two-stream fork/join (tens of us on the 6000

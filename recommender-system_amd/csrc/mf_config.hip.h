@@ -33,6 +33,8 @@ struct mf_config {
 	bool rec_exact = false;           // MF_RECOMMEND_IMPL=exact: the exact recommendation kernel only
 	bool rec_ares = true;             // MF_RECOMMEND_ARES=0: no LDS-resident L image in the MFMA pass
 	bool rec_bdma = true;             // MF_RECOMMEND_BDMA=0: R chunks staged through registers
+	int rec_half = 1;                 // MF_RECOMMEND_HALF=0: no 64-user workgroups (two per CU) in the MFMA pass; all: also for
+	                                  // K that is no multiple of 20 (the general form of that kernel: slower than the 128-user one)
 	int rec_split = -1;               // MF_RECOMMEND_SPLIT=0|n: item split of small recommendations off / n splits (-1: rule)
 	bool build_host = false;          // MF_BUILD=host: CSR/CSC bucketed on the host
 	bool os_dpp = true;               // MF_OS_DPP=0: ordered sums by plain v_add_f64 (no DPP broadcast)
@@ -52,6 +54,7 @@ struct mf_config {
 	int db_rows = 0;                  // MF_SWEEP_DB_ROWS: row count below which the double-buffered sweep is chosen (0: rule)
 	int sweep_long_kind[2] = {0, 0};  // MF_SWEEP_LONG_I / MF_SWEEP_LONG_U: the extreme-row threshold of the item / user sweep alone
 	int side_prio = -1;               // MF_SIDE_PRIO=0|1: the side stream of the extreme-row path at low / high priority (-1: rule)
+	int pf_rows = 0;                  // MF_SWEEP_PF_ROWS: launches of up to this many rows take the pipelined-phases form (0: 262144)
 	int pair_loaders = 0;             // MF_SWEEP_PAIR_LOADERS=1|2: loader waves of the wave-pair form (0: rule)
 	int pair_nch = 0;                 // MF_SWEEP_PAIR_NCH: chunk size of the wave-pair form (0: 32)
 	int db_nch = 0;                   // MF_SWEEP_DB_NCH: its chunk size (0: 16)
@@ -89,6 +92,7 @@ struct mf_config {
 		c.rec_exact = eq(getenv("MF_RECOMMEND_IMPL"), "exact");
 		c.rec_ares = !is0(getenv("MF_RECOMMEND_ARES"));
 		c.rec_bdma = !is0(getenv("MF_RECOMMEND_BDMA"));
+		if ((v = getenv("MF_RECOMMEND_HALF"))) c.rec_half = is0(v) ? 0 : eq(v, "all") ? 2 : 1;
 		if ((v = getenv("MF_RECOMMEND_SPLIT"))) c.rec_split = atoi(v);
 		c.build_host = eq(getenv("MF_BUILD"), "host");
 		c.os_dpp = !is0(getenv("MF_OS_DPP"));
@@ -109,6 +113,7 @@ struct mf_config {
 		if ((v = getenv("MF_SWEEP_DB_NCH"))) c.db_nch = atoi(v);
 		if ((v = getenv("MF_SWEEP_PAIR_NCH"))) c.pair_nch = atoi(v);
 		if ((v = getenv("MF_SWEEP_PAIR_LOADERS"))) c.pair_loaders = atoi(v);
+		if ((v = getenv("MF_SWEEP_PF_ROWS"))) c.pf_rows = atoi(v);
 		if ((v = getenv("MF_SWEEP_LONG_I"))) c.sweep_long_kind[0] = atoi(v);
 		if ((v = getenv("MF_SWEEP_LONG_U"))) c.sweep_long_kind[1] = atoi(v);
 		if ((v = getenv("MF_SIDE_PRIO"))) c.side_prio = is0(v) ? 0 : 1;
@@ -142,6 +147,7 @@ struct mf_config {
 		if (rec_exact) add("MF_RECOMMEND_IMPL", "exact");
 		if (!rec_ares) add("MF_RECOMMEND_ARES", "0");
 		if (!rec_bdma) add("MF_RECOMMEND_BDMA", "0");
+		if (rec_half != 1) add("MF_RECOMMEND_HALF", rec_half ? "all" : "0");
 		if (rec_split >= 0) add("MF_RECOMMEND_SPLIT", std::to_string(rec_split));
 		if (build_host) add("MF_BUILD", "host");
 		if (!os_dpp) add("MF_OS_DPP", "0");
@@ -161,6 +167,7 @@ struct mf_config {
 		if (db_nch) add("MF_SWEEP_DB_NCH", std::to_string(db_nch));
 		if (pair_nch) add("MF_SWEEP_PAIR_NCH", std::to_string(pair_nch));
 		if (pair_loaders) add("MF_SWEEP_PAIR_LOADERS", std::to_string(pair_loaders));
+		if (pf_rows) add("MF_SWEEP_PF_ROWS", std::to_string(pf_rows));
 		if (sweep_long_kind[0]) add("MF_SWEEP_LONG_I", std::to_string(sweep_long_kind[0]));
 		if (sweep_long_kind[1]) add("MF_SWEEP_LONG_U", std::to_string(sweep_long_kind[1]));
 		if (side_prio >= 0) add("MF_SIDE_PRIO", std::to_string(side_prio));

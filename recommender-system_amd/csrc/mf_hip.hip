@@ -505,15 +505,33 @@ static int launch_recommend_pass1(mf_plan *p, mf_filter *filt)
 	else
 		fn = ares ? (vec ? mf::recommend_mfma_kernel<true, 32, true> : mf::recommend_mfma_kernel<false, 32, true>)
 		          : (vec ? mf::recommend_mfma_kernel<true, 32, false> : mf::recommend_mfma_kernel<false, 32, false>);
-	const size_t lds = mf::rec_mfma_lds(p->K, kc, ares);
+	size_t lds = mf::rec_mfma_lds(p->K, kc, ares);
+	// K = 20, 40, .. 100 (a wave's L operand fits its registers; whole 20-deep chunks): workgroups of 64 users, two per CU,
+	// whose barriers / arg-max steps / mask walks overlap each other's matrix instructions, with a gapless matrix stream
+	// per wave.  K=100: 64.7 vs 57.6 TFLOP/s on the 131072 x 100000 probe, K=80 64.3 vs 57.4, K=40 57.7 vs 52.1, K=20 49.7 vs
+	// 45.0.  Its general form (any even K <= 100, MF_RECOMMEND_HALF=all) has branches on K in the tile body that defeat
+	// hipcc's s_waitcnt placement and is slower than the 128-user kernel (K=64: 51.7 vs 58.5): not chosen by the rule.
+	const bool half = vec && allow_dma && p->cfg.rec_half && p->K <= mf::kHKmax && (p->K % mf::kHKC == 0 || p->cfg.rec_half == 2) &&
+	                  (unsigned long long) p->items * (unsigned long long) p->ldr * 8ull < (1ull << 32);   // 32-bit row offsets
+	int block_users = mf::kMU, threads = mf::kMThreads;
+	if (half) {
+		static const RecFn whole[6] = {mf::recommend_mfma2_kernel<0>, mf::recommend_mfma2_kernel<1>, mf::recommend_mfma2_kernel<2>,
+		                               mf::recommend_mfma2_kernel<3>, mf::recommend_mfma2_kernel<4>, mf::recommend_mfma2_kernel<5>};
+		fn = whole[p->K % mf::kHKC == 0 ? p->K / mf::kHKC : 0];
+		lds = mf::rec_mfma2_lds();
+		block_users = mf::kHU;
+		threads = mf::kHThreads;
+	}
+	p->rec_half_used = half;
 	MF_HIP(raise_lds_limit((const void *) fn, lds));
-	// Small problems: a workgroup owns 128 users and ALL items, so few users leave most of the chip idle (cfg3: 48
+	// Small problems: a workgroup owns 128 (64) users and ALL items, so few users leave most of the chip idle (cfg3: 48
 	// workgroups on 256 CUs).  The items are then split over gridDim.y -- whole 128-item tiles, about two workgroups per
-	// CU in all -- and the per-split top-2 reports merged and certified by merge_splits_kernel.
-	const int ublocks = (p->uc + mf::kMU - 1) / mf::kMU, tiles = (p->items + mf::kMI - 1) / mf::kMI;
+	// CU in all (four of the half-size ones) -- and the per-split top-2 reports merged and certified by merge_splits_kernel.
+	const int ublocks = (p->uc + block_users - 1) / block_users, tiles = (p->items + mf::kMI - 1) / mf::kMI;
+	const int chip = half ? 1024 : 512;
 	int nsplit = 1;
-	if (p->cfg.rec_split != 0 && ublocks < 192 && tiles >= 2) {
-		nsplit = p->cfg.rec_split > 0 ? p->cfg.rec_split : (512 + ublocks - 1) / ublocks;
+	if (p->cfg.rec_split != 0 && ublocks < chip * 3 / 8 && tiles >= 2) {
+		nsplit = p->cfg.rec_split > 0 ? p->cfg.rec_split : (chip + ublocks - 1) / ublocks;
 		nsplit = std::max(1, std::min(nsplit, tiles));
 	}
 	m.split_items = 0;
@@ -532,7 +550,7 @@ static int launch_recommend_pass1(mf_plan *p, mf_filter *filt)
 		}
 		m.part = p->part_dev;
 	}
-	hipLaunchKernelGGL(fn, dim3(ublocks, nsplit), dim3(mf::kMThreads), lds, p->stream, m);
+	hipLaunchKernelGGL(fn, dim3(ublocks, nsplit), dim3(threads), lds, p->stream, m);
 	MF_HIP(hipGetLastError());
 	if (nsplit > 1) {
 		hipLaunchKernelGGL(mf::merge_splits_kernel, dim3((p->uc + 255) / 256), dim3(256), 0, p->stream, m, nsplit);
@@ -862,6 +880,16 @@ int mf_debug_read_stamps(unsigned long long *out8)
 	MF_HIP(hipDeviceSynchronize());
 	MF_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(mf::mf_stamp_buf), sizeof zero));
 	MF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(mf::mf_stamp_buf), zero, sizeof zero));
+	return MF_OK;
+}
+
+// the same for recommend_mfma_kernel (tools/rec_stamps.py): waves 0 and 7 of workgroup 0
+int mf_debug_read_rec_stamps(unsigned long long *out32)
+{
+	unsigned long long zero[32] = {};
+	MF_HIP(hipDeviceSynchronize());
+	MF_HIP(hipMemcpyFromSymbol(out32, HIP_SYMBOL(mf::mf_rec_stamp_buf), sizeof zero));
+	MF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(mf::mf_rec_stamp_buf), zero, sizeof zero));
 	return MF_OK;
 }
 #endif

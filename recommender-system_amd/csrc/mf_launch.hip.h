@@ -1,5 +1,6 @@
 // mf_launch.hip.h -- choice of the sweep kernel variant / chunk size and the launch of one sweep.
 #pragma once
+#include <climits>
 
 namespace {
 
@@ -180,9 +181,11 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 	const size_t lds = coop ? p->lds_bytes_coop : db ? p->lds_bytes_db : pair ? p->lds_bytes_pair : (few_rows ? p->lds_bytes_few : p->lds_bytes);
 	// Accumulate form of the single-wave launch.  Up to kPfRows rows: the form whose phases keep their LDS reads in flight
 	// and whose gather issue is lean -- what a wave walking a long row alone is bound by (cfg3 uniform 0.224 -> 0.201 ms,
-	// power-law 0.367 -> 0.350, a lone 5993-entry row 1.02 -> 0.78 ms).  Larger launches are never bound by one wave and
-	// keep round 2's form (cfg4 user sweep, 1e6 rows: 11.45 vs 11.60 ms).
-	constexpr int kPfRows = 262144;
+	// power-law 0.367 -> 0.350, a lone 5993-entry row 1.02 -> 0.78 ms).  Larger launches of one-pass rows (K <= 128) are
+	// never bound by one wave and keep round 2's form (cfg4 user sweep, 1e6 rows: 11.45 vs 11.60 ms).  Two-pass rows
+	// (K = 256) take it at every size: their phase A is a 256-deep chain per chunk that the six resident workgroups of a
+	// CU do not hide, and keeping its LDS reads in flight shortens it (cfg5: 346.6 -> 327.9 ms, 0.745 -> 0.787).
+	const int kPfRows = p->cfg.pf_rows > 0 ? p->cfg.pf_rows : (p->K > 128 ? INT_MAX : 262144);
 	const SweepFn single = p->sweep.pf && p->n_short[kind] <= kPfRows && a.nrows <= kPfRows ? p->sweep.pf : p->sweep.fn;
 	const SweepFn fn = coop ? p->sweep.coop : db ? p->sweep.db : pair ? p->sweep.pair : single;
 	const int block = coop ? mf::kCoopWaves * mf::kWave : pair ? (p->pair_loaders + 1) * mf::kWave : mf::kWave;

@@ -159,6 +159,7 @@ struct mf_plan {
 	mf_filter *filt_dev = nullptr;      // recommend_filter output, allocated on first use
 	mf_filter *part_dev = nullptr;      // per-split reports of a small recommendation (nsplit x users), allocated on first use
 	int part_cap = 0;
+	bool rec_half_used = false;   // the last MFMA pass ran as 64-user workgroups, two per CU (recommend_mfma2_kernel)
 	int cur = 0;            // generation index of the current factors
 	bool have_factors = false;
 	int *best_dev = nullptr;

@@ -289,6 +289,15 @@ __device__ __forceinline__ void top2_merge(Top2 &a, const Top2 &b)
 
 typedef double mf_d4 __attribute__((ext_vector_type(4)));
 
+#ifdef MF_STAMPS
+// diagnostic build only (tools/rec_stamps.py): shader-clock totals of wave 0 (slots 0..15) and wave 7 (16..31) of workgroup 0 --
+// [0] tiles, [1] chunks, [2] mask walk, [3] prefetch issue, [4] k-steps, [5] landing wait, [6] barrier, [7] arg-max, [8] kernel
+__device__ unsigned long long mf_rec_stamp_buf[32];
+#define MF_RSTAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define MF_RSTAMP(var)
+#endif
+
 // 512 threads = 8 waves as 4 (user quarters of 32) x 2 (item halves of 64): two waves per SIMD, so one
 // wave's staging, LDS traffic and arg-max bookkeeping run under the other's matrix instructions.
 //   VEC   K even -> rows are 16-B aligned, 16-byte global loads
@@ -439,6 +448,10 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 	const int j_first = a.split_items ? (int) blockIdx.y * a.split_items : 0;
 	const int j_end = a.split_items ? min(a.items, j_first + a.split_items) : a.items;
 	int buf = 0;
+#ifdef MF_STAMPS
+	unsigned long long rs_tiles = 0, rs_chunks = 0, rs_mask = 0, rs_issue = 0, rs_k = 0, rs_land = 0, rs_bar = 0, rs_arg = 0;
+#endif
+	MF_RSTAMP(rt_begin);
 	if (BDMA) {
 		dma_chunk(j_first, 0, 0);
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -464,6 +477,7 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 		// Written at the START of the tile into the parity's copy: the chunk barriers below publish it before the
 		// arg-max step reads it, and the other parity is not rewritten before every wave has passed them again.
 		const int par = ((j0 - j_first) / kMI) & 1;
+		MF_RSTAMP(rt_m0);
 		if (tid < kMU) {
 			unsigned long long m0 = 0, m1 = 0;
 			while (nextcol < j0 + kMI) {
@@ -486,10 +500,15 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 			maskw[par][tid][0] = m0;
 			maskw[par][tid][1] = m1;
 		}
+#ifdef MF_STAMPS
+		rs_mask += __builtin_amdgcn_s_memtime() - rt_m0;
+		++rs_tiles;
+#endif
 
 		for (int kc = 0; kc < K; kc += KC) {
 			// next chunk (of this tile, or the first of the next tile): global loads fly behind the MFMAs
 			const bool more = kc + KC < K || j0 + kMI < j_end;
+			MF_RSTAMP(rt_c0);
 			if (BDMA) {   // straight into the OTHER buffer (last read one chunk ago; every wave passed a barrier since)
 				if (kc + KC < K)
 					dma_chunk(j0, kc + KC, buf ^ 1);
@@ -501,6 +520,7 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 				fetch(j0 + kMI, 0);
 			const double *Ab = reinterpret_cast<const double *>(rec_lds + (ARES ? (kc / KC) : buf) * kChunkD2);
 			const double *Bb = reinterpret_cast<const double *>(Bs0 + buf * kChunkD2);
+			MF_RSTAMP(rt_c1);
 			auto kstep = [&](int ks) {
 				// k = 4*ks + lq -> pair 2*ks + (lq >> 1), half lq & 1
 				const int po = ((2 * ks + (lq >> 1)) * kMLD2) * 2 + (lq & 1);
@@ -523,32 +543,405 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 				for (int ks = 0; ks < ksteps; ++ks) kstep(ks);
 			}
 			// registers -> the OTHER buffer (last read one chunk ago; every wave passed a barrier since)
+			MF_RSTAMP(rt_c2);
 			if (BDMA)
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			else if (more)
 				stage(buf ^ 1);
+			MF_RSTAMP(rt_c3);
 			__syncthreads();
+#ifdef MF_STAMPS
+			rs_issue += rt_c1 - rt_c0;
+			rs_k += rt_c2 - rt_c1;
+			rs_land += rt_c3 - rt_c2;
+			rs_bar += __builtin_amdgcn_s_memtime() - rt_c3;
+			++rs_chunks;
+#endif
 			buf ^= 1;
 		}
+		MF_RSTAMP(rt_e0);
 
+		// Cheap reject: after the first tiles almost no score beats its row's runner-up.  One compare per score register,
+		// masks not even looked at: the 32 lane masks land in scalar registers and are OR-ed there, one scalar branch decides
+		// (fmax() would add a canonicalising v_max per operand, a ballot two more vector instructions per row -- and every
+		// vector instruction of this step waits for the matrix pipe of its SIMD).  !(v <= thr) is also true for a NaN.  Only
+		// when the norms do not rule out non-finite scores (all_finite) a sum per row is formed as well: it is non-finite
+		// whenever a score is NaN or +-inf (a sum that merely overflows only costs the slow path).
+		constexpr int kUGT = 10;   // llvm::FCmpInst::FCMP_UGT: unordered or greater than
+		unsigned long long rowm[8];
+		unsigned long long anym = 0;
 #pragma unroll
 		for (int tu = 0; tu < 2; ++tu)
 #pragma unroll
 			for (int r = 0; r < 4; ++r) {
 				const int x = tu * 4 + r;
-				// cheap reject: after the first tiles almost no score beats the row's runner-up.  One maximum over the
-				// lane's four scores of the row, masks not even looked at: max <= runner-up means no candidate
-				// whatever is rated.  Only when the norms do not rule out non-finite scores (all_finite) a sum is
-				// formed as well: it is non-finite whenever a score is NaN or +-inf (max would drop a NaN; a sum that
-				// merely overflows only costs the slow path).
-				const double v0 = acc[tu][0][r], v1 = acc[tu][1][r], v2 = acc[tu][2][r], v3 = acc[tu][3][r];
-				const double vmax = fmax(fmax(v0, v1), fmax(v2, v3));
-				bool any = !(vmax <= thr2[x]);
-				if (!all_finite) any |= !(fabs((v0 + v1) + (v2 + v3)) <= 1.7976931348623157e308);
-				if (__builtin_amdgcn_ballot_w64(any) != 0) {
+				rowm[x] = __builtin_amdgcn_fcmp(acc[tu][0][r], thr2[x], kUGT) | __builtin_amdgcn_fcmp(acc[tu][1][r], thr2[x], kUGT) |
+				          __builtin_amdgcn_fcmp(acc[tu][2][r], thr2[x], kUGT) | __builtin_amdgcn_fcmp(acc[tu][3][r], thr2[x], kUGT);
+				anym |= rowm[x];
+			}
+		if (!all_finite) {
+#pragma unroll
+			for (int tu = 0; tu < 2; ++tu)
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					const double sum = (acc[tu][0][r] + acc[tu][1][r]) + (acc[tu][2][r] + acc[tu][3][r]);
+					rowm[tu * 4 + r] |= __builtin_amdgcn_fcmp(fabs(sum), 1.7976931348623157e308, kUGT);
+					anym |= rowm[tu * 4 + r];
+				}
+		}
+		if (anym != 0)
+#pragma unroll
+		for (int tu = 0; tu < 2; ++tu)
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const int x = tu * 4 + r;
+				if (rowm[x] != 0) {
 					// slow path (the whole wave, a few dozen times per row over the kernel): the lane's top-2 of the
 					// row among its unrated items, merged over the 16 lanes that share the row, folded into the
 					// row's state in LDS by the first of them, and the new runner-up handed back to all 16
+					const int row = 32 * wr + 16 * tu + lq + 4 * r;
+					const unsigned long long m = maskw[par][row][wc] >> lr;
+					Top2 t{ninf, ninf, -1};
+					int bd = 0;
+#pragma unroll
+					for (int ti = 0; ti < 4; ++ti) {
+						const double v = acc[tu][ti][r];
+						const bool open = !((m >> (16 * ti)) & 1ull);
+						const bool fin = fabs(v) <= 1.7976931348623157e308;
+						bd |= open && !fin;
+						if (open && fin) top2_merge(t, Top2{v, ninf, j0 + 64 * wc + 16 * ti + lr});
+					}
+#pragma unroll
+					for (int d = 1; d < 16; d <<= 1) {
+						Top2 o;
+						o.b1 = __shfl_xor(t.b1, d, 16);
+						o.b2 = __shfl_xor(t.b2, d, 16);
+						o.i1 = __shfl_xor(t.i1, d, 16);
+						bd |= __shfl_xor(bd, d, 16);
+						top2_merge(t, o);
+					}
+					if (lr == 0) {
+						Top2 st{red_b1[row][wc], red_b2[row][wc], red_i1[row][wc]};
+						top2_merge(st, t);
+						red_b1[row][wc] = st.b1;
+						red_b2[row][wc] = st.b2;
+						red_i1[row][wc] = st.i1;
+						if (bd) red_bad[row][wc] = 1;
+						t.b2 = st.b2;
+					}
+					thr2[x] = __shfl(t.b2, lane & ~15);
+				}
+			}
+#ifdef MF_STAMPS
+		rs_arg += __builtin_amdgcn_s_memtime() - rt_e0;
+#endif
+	}
+#ifdef MF_STAMPS
+	if (blockIdx.x == 0 && blockIdx.y == 0 && (tid == 0 || tid == 7 * 64)) {
+		unsigned long long *o = mf_rec_stamp_buf + (tid ? 16 : 0);
+		o[0] += rs_tiles; o[1] += rs_chunks; o[2] += rs_mask; o[3] += rs_issue; o[4] += rs_k; o[5] += rs_land; o[6] += rs_bar;
+		o[7] += rs_arg; o[8] += __builtin_amdgcn_s_memtime() - rt_begin;
+	}
+#endif
+
+	// merge the two item halves (wc) of every row, then decide
+	__syncthreads();
+	if (tid < kMU && i0 + tid < a.users) {
+		Top2 t{red_b1[tid][0], red_b2[tid][0], red_i1[tid][0]};
+		const Top2 o{red_b1[tid][1], red_b2[tid][1], red_i1[tid][1]};
+		top2_merge(t, o);
+		const int bd = red_bad[tid][0] | red_bad[tid][1];
+		if (a.split_items) {   // certification over the splits: merge_splits_kernel
+			a.part[(size_t) blockIdx.y * a.users + i0 + tid] = mf_filter{t.b1, t.b2, t.i1, bd};
+			return;
+		}
+		if (a.filt) {   // certification is the caller's, over several item blocks
+			a.filt[i0 + tid] = mf_filter{t.b1, t.b2, t.i1, bd};
+			return;
+		}
+		const double rmax = __longlong_as_double((long long) *a.rnorm_max_bits);
+		const double thr = a.thr_scale * a.lnorm[i0 + tid] * rmax + 1e-300;
+		const bool certain = !bd && (t.i1 < 0 || (t.b1 - t.b2) > thr);
+		if (certain) {
+			a.best[i0 + tid] = t.i1;
+		} else {
+			a.best[i0 + tid] = -2;
+			a.ulist[atomicAdd(a.ucount, 1)] = i0 + tid;
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Recommend kernel, MFMA form, TWO WORKGROUPS PER CU with the L fragments IN REGISTERS (even K <= 100: the headline
+// configuration).  recommend_mfma_kernel keeps one 8-wave workgroup per CU: every chunk barrier, the arg-max step of a
+// finished tile and the rated-item walk stop BOTH waves of every SIMD at the same moment, and the matrix pipe idles
+// until the first fragment of the next chunk is back (clocks of waves 0 and 7, tools/rec_stamps.py: 34.8 k cycles per
+// tile against the 25.6 k of its 2 x 25 x 8 matrix instructions; ~0.5-0.7 k idle around each of 5 barriers, ~2 k
+// arg-max, 0.7 k masks).  Here a workgroup is 4 waves = 64 users x 128 items per step, ONE wave per SIMD, and two
+// workgroups share a CU: the second wave of every SIMD belongs to the OTHER workgroup, which has its own barriers, so
+// one workgroup's barrier, arg-max or mask walk runs under the other's matrix instructions -- no new synchronisation,
+// just independent phases.  What makes two fit: a wave's L operand -- 32 users x K, the same for every item tile --
+// lives in REGISTERS (2 doubles per lane and k-step: 100 VGPRs at K=100, beside 64 accumulators), so LDS holds only a
+// ring of three 20-deep R chunks (10 k-pairs x 128 items x 16 B = 20 KB each): 60 KB per workgroup.  The transfer of
+// chunk s+2 is issued under the matrix instructions of chunk s -- a chunk has two chunk times to land --, fragment reads
+// per matrix instruction drop from 6/8 to 4/8, and the images need no padding rows (written only by LDS-DMA, 1 KB
+// contiguous per instruction; the fragment read of 32 lanes is 256 contiguous bytes).  R streams from L2 twice as often
+// (64 users per pass instead of 128): 3.8 TB/s of L2 -> LDS at cfg4, HBM traffic unchanged (the workgroups of an XCD
+// walk R = 80 MB in step).  Masks, top-2 bookkeeping and certification are those of recommend_mfma_kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int kHU = 64, kHThreads = 256, kHKC = 20, kHPC = kHKC / 2, kHQ = kHKC / 4, kHNB = 3, kHKmax = 100;
+constexpr int kHChunkD2 = kHPC * kMI;   // double2 elements of one R chunk image: [k-pair][128 items]
+constexpr size_t kHStaticLds = 2 * kHU * 2 * 8 + kHU * 2 * (8 + 8 + 4 + 4) + 64;
+inline size_t rec_mfma2_lds() { return (size_t) kHNB * kHChunkD2 * sizeof(double2); }
+
+// NC > 0: K == 20 * NC exactly -- every chunk whole, no branch of the tile body depends on K (hipcc's s_waitcnt placement
+// follows the fragment pipeline only through straight-line code); NC == 0: any even K <= 100.
+template <int NC>
+__global__ void __launch_bounds__(kHThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) recommend_mfma2_kernel(RecMfmaArgs a)
+{
+	constexpr int NCH = NC ? NC : kHKmax / kHKC, KSTEPS = NCH * kHQ;
+	extern __shared__ double2 rec_lds[];   // ring of kHNB R chunks: [k-pair][128 items]
+	const int K = a.K;
+	__shared__ unsigned long long maskw[2][kHU][2];   // [tile parity][user][item half]
+	__shared__ double red_b1[kHU][2], red_b2[kHU][2];
+	__shared__ int red_i1[kHU][2], red_bad[kHU][2];
+	__shared__ unsigned long long lmax_bits;
+
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wr = wave >> 1, wc = wave & 1;
+	const int lr = lane & 15, lq = lane >> 4;
+	const int i0 = blockIdx.x * kHU;
+	const double ninf = -__builtin_inf();
+
+	// mask walker: wave 0, one user per lane, the next two rated items held in registers (recommend_mfma_kernel)
+	int cur = 0, cend = 0, nextcol = INT32_MAX, nextcol2 = INT32_MAX;
+	if (tid < kHU && i0 + tid < a.users) {
+		cur = a.csr_ptr[i0 + tid];
+		cend = a.csr_ptr[i0 + tid + 1];
+		nextcol = cur < cend ? a.csr_idx[cur] : INT32_MAX;
+		nextcol2 = cur + 1 < cend ? a.csr_idx[cur + 1] : INT32_MAX;
+	}
+	double thr2[8];   // runner-up of each of the lane's 8 rows: row(tu, r) = 32*wr + 16*tu + lq + 4*r
+#pragma unroll
+	for (int x = 0; x < 8; ++x) thr2[x] = ninf;
+	if (tid < kHU) {
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			red_b1[tid][h] = ninf;
+			red_b2[tid][h] = ninf;
+			red_i1[tid][h] = -1;
+			red_bad[tid][h] = 0;
+		}
+		unsigned long long b = i0 + tid < a.users ? (unsigned long long) __double_as_longlong(a.lnorm[i0 + tid]) : 0ull;
+		for (int d = 32; d >= 1; d >>= 1) {
+			const unsigned long long o = __shfl_xor(b, d);
+			b = o > b ? o : b;
+		}
+		if (lane == 0) lmax_bits = b;
+	}
+	// pairs beyond K are never transferred: the ring holds zeros there at first, not NaN patterns
+	for (int sl = tid; sl < kHNB * kHChunkD2; sl += kHThreads) rec_lds[sl] = make_double2(0.0, 0.0);
+	// the wave's L operand, once: k-step ks, user tile tu -> A[32*wr + 16*tu + lr][4*ks + lq] (zero beyond K / the last user)
+	double fa[KSTEPS][2];
+#pragma unroll
+	for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+		for (int tu = 0; tu < 2; ++tu) {
+			const int row = i0 + 32 * wr + 16 * tu + lr, k = 4 * ks + lq;
+			fa[ks][tu] = row < a.users && k < K ? a.L[(size_t) row * a.ldl + k] : 0.0;
+		}
+	__syncthreads();
+
+	// LDS-DMA of one R chunk (k offset kc of the tile `voff` points into) into ring slot `slot`: 20 instructions of 64
+	// rows x 16 B, five per wave (k-pair wr + 2h, rows 64*wc..+63).  Scalar base + per-lane row offset: no vector
+	// arithmetic per transfer -- every VALU instruction of a wave waits for the matrix pipe of its SIMD to drain
+	// (tools/micro/valu_under_mfma.hip).  Returns how many this wave issued (pairs beyond K: none).
+	const unsigned bs_lds = (unsigned) (unsigned long long) (__attribute__((address_space(3))) char *) rec_lds;
+	unsigned voff = 0;
+	auto set_rows = [&](int jt) {
+		// lane i of a transfer lands at byte 16 i of window w = wc of its k-pair's row: the item the chunk image keeps there
+		const int item = ((lane >> 4) & 1) * 64 + (2 * wc + (lane >> 5)) * 16 + (lane & 15);
+		const int row = min(jt + item, a.items - 1);      // rows beyond the matrix are masked
+		voff = (unsigned) row * (unsigned) (a.ldr * 8);   // the host admits R below 4 GB only
+	};
+	auto dma_chunk = [&](int kc, int slot) -> int {
+		int n = 0;
+#pragma unroll
+		for (int h = 0; h < kHPC / 2; ++h) {
+			const int pr = wr + 2 * h, k = kc + 2 * pr;
+			if (k < K) {   // wave-uniform
+				const char *sbase = reinterpret_cast<const char *>(a.R + k);
+				const unsigned m0 = bs_lds + (unsigned) ((slot * kHChunkD2 + pr * kMI + 64 * wc) * 16);
+				asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m0));
+				++n;
+			}
+		}
+		return n;
+	};
+	// at most n of this wave's transfers still in flight (hipcc does not count the asm transfers)
+	auto wait_vm = [&](int n) {
+		switch (n) {
+		case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+		case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+		case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+		case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+		case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+		default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+		}
+	};
+
+	const int j_first = a.split_items ? (int) blockIdx.y * a.split_items : 0;
+	const int j_end = a.split_items ? min(a.items, j_first + a.split_items) : a.items;
+	// the chunk sequence: tiles in ascending order, k-chunks within; (pj, pk, pslot) = the next chunk to transfer
+	int pj = j_first, pk = 0, pslot = 0;
+	auto issue_next = [&]() -> int {
+		if (pj >= j_end) return 0;
+		if (pk == 0) set_rows(pj);
+		const int n = dma_chunk(pk, pslot);
+		pk += kHKC;
+		if (pk >= K) {
+			pk = 0;
+			pj += kMI;
+		}
+		pslot = pslot == kHNB - 1 ? 0 : pslot + 1;
+		return n;
+	};
+	issue_next();
+	wait_vm(issue_next());   // chunk 0 has landed; chunk 1 may still be in flight
+	__syncthreads();
+	bool all_finite;
+	{
+		const double bound = __longlong_as_double((long long) lmax_bits) * __longlong_as_double((long long) *a.rnorm_max_bits);
+		all_finite = bound <= 1e300;   // false for NaN
+	}
+	// R fragment of k-step q of the chunk in ring slot s: k = 4q + lq -> pair 2q + (lq >> 1), half lq & 1.  Within the 2 KB
+	// row of a k-pair, item 64 wc + 16 ti + lr sits at byte 512 ti + 256 wc + 16 lr: a wave's four fragments of a k-step are
+	// 512 B apart, the k-steps 4 KB, the slots 20 KB -- all multiples of 512, so every fragment read of a chunk is one base
+	// register plus an immediate (ds_read2st64_b64) and the k-loop holds no vector arithmetic at all.
+	const int boff = (lq >> 1) * (kMI * 2) + wc * 32 + lr * 2 + (lq & 1);
+	auto frag = [&](int s, int q, double (&f)[4]) {
+		const double *Bb = reinterpret_cast<const double *>(rec_lds) + s * (kHChunkD2 * 2) + boff;
+#pragma unroll
+		for (int ti = 0; ti < 4; ++ti) f[ti] = Bb[(8 * q + ti) * 64];
+	};
+	// The matrix stream of a wave has no gap of its own: the fragment of the NEXT k-step -- of this chunk, of the next
+	// chunk, of the next tile -- is read in front of the matrix instructions of the current one.  For that the barrier
+	// that publishes chunk s+1 stands in front of the LAST k-step of chunk s (whose transfer, issued under the first k-step
+	// of chunk s-1, has had almost two chunk times), and the transfer of chunk s+2 goes into the slot of chunk s-1 -- whose
+	// last fragment every wave had read before it passed that barrier one chunk ago.
+	double fc[4];
+	frag(0, 0, fc);
+	int slot = 0, pending = 0;   // pending: this wave's transfers issued AFTER those of the chunk the next barrier publishes
+	for (int j0 = j_first; j0 < j_end; j0 += kMI) {
+		mf_d4 acc[2][4];
+
+		// rated-item mask of this tile into the parity's copy; published by the chunk barriers below, and the other
+		// parity is not rewritten before every wave has passed them again (recommend_mfma_kernel)
+		const int par = ((j0 - j_first) / kMI) & 1;
+		if (tid < kHU) {
+			unsigned long long m0 = 0, m1 = 0;
+			while (nextcol < j0 + kMI) {
+				const int o = nextcol - j0;
+				if (o >= 64)
+					m1 |= 1ull << (o - 64);
+				else if (o >= 0)
+					m0 |= 1ull << o;
+				++cur;
+				nextcol = nextcol2;
+				nextcol2 = cur + 1 < cend ? a.csr_idx[cur + 1] : INT32_MAX;
+			}
+			const int left = j_end - j0;   // > 0
+			if (left < 64) {
+				m0 |= ~0ull << left;
+				m1 = ~0ull;
+			} else if (left < 128) {
+				m1 |= ~0ull << (left - 64);
+			}
+			maskw[par][tid][0] = m0;
+			maskw[par][tid][1] = m1;
+		}
+
+#pragma unroll
+		for (int c = 0; c < NCH; ++c) {
+			const int kc = c * kHKC;
+			if (NC || kc < K) {   // wave-uniform
+				const int nq = NC ? kHQ : min(kHQ, (K - kc + 3) >> 2);   // k-steps of this chunk (only the last chunk can be short)
+				const int nslot = slot == kHNB - 1 ? 0 : slot + 1;
+#pragma unroll
+				for (int q = 0; q < kHQ; ++q) {
+					if (q < nq) {   // wave-uniform
+						double fn[4];
+						if (q == nq - 1) {
+							wait_vm(pending);   // chunk s+1 has landed ...
+							pending = 0;
+#ifndef MF_REC_NOBAR
+							__syncthreads();    // ... for every wave
+#endif
+							frag(nslot, 0, fn);
+						} else {
+							frag(slot, q + 1, fn);
+						}
+						// the reads stay in front of the matrix instructions (the scheduler would sink them behind the last
+						// use of the current fragment's registers to save eight VGPRs -- and expose the LDS latency per k-step)
+						__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+						for (int tu = 0; tu < 2; ++tu)
+#pragma unroll
+							for (int ti = 0; ti < 4; ++ti)
+								acc[tu][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[c * kHQ + q][tu], fc[ti],
+								                                                   c + q == 0 ? mf_d4{0.0, 0.0, 0.0, 0.0} : acc[tu][ti], 0, 0, 0);
+						if (q == 0) {   // chunk s+2 under the matrix instructions just issued
+							const int n = issue_next();
+							if (q != nq - 1) pending = n;
+						}
+#pragma unroll
+						for (int ti = 0; ti < 4; ++ti) fc[ti] = fn[ti];
+					}
+				}
+				slot = nslot;
+			}
+		}
+
+		// Cheap reject: after the first tiles almost no score beats its row's runner-up.  Every vector instruction of this
+		// step costs matrix-pipe time (nothing else of the SIMD runs while an FP64 matrix instruction executes, and vice
+		// versa), so the common case is ONE compare per score register -- 32 v_cmp whose lane masks land in scalar registers
+		// and are OR-ed there -- and one scalar branch; fmax() would add a canonicalising v_max per operand and a ballot two
+		// more instructions per row.  (!(v <= thr) is also true for a NaN.)  Only when the norms do not rule out non-finite
+		// scores a sum per row is formed as well: it is non-finite whenever a score is NaN or +-inf.
+		constexpr int kUGT = 10;   // llvm::FCmpInst::FCMP_UGT: unordered or greater than
+		unsigned long long rowm[8];
+		unsigned long long anym = 0;
+#pragma unroll
+		for (int tu = 0; tu < 2; ++tu)
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const int x = tu * 4 + r;
+				rowm[x] = __builtin_amdgcn_fcmp(acc[tu][0][r], thr2[x], kUGT) | __builtin_amdgcn_fcmp(acc[tu][1][r], thr2[x], kUGT) |
+				          __builtin_amdgcn_fcmp(acc[tu][2][r], thr2[x], kUGT) | __builtin_amdgcn_fcmp(acc[tu][3][r], thr2[x], kUGT);
+				anym |= rowm[x];
+			}
+		if (!all_finite) {
+#pragma unroll
+			for (int tu = 0; tu < 2; ++tu)
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					const double sum = (acc[tu][0][r] + acc[tu][1][r]) + (acc[tu][2][r] + acc[tu][3][r]);
+					rowm[tu * 4 + r] |= __builtin_amdgcn_fcmp(fabs(sum), 1.7976931348623157e308, kUGT);
+					anym |= rowm[tu * 4 + r];
+				}
+		}
+#ifdef MF_REC_NOEPI
+		if (j0 + kMI >= j_end)
+#endif
+		if (anym != 0)
+#pragma unroll
+		for (int tu = 0; tu < 2; ++tu)
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const int x = tu * 4 + r;
+				// slow path exactly as in recommend_mfma_kernel
+				if (rowm[x] != 0) {
 					const int row = 32 * wr + 16 * tu + lq + 4 * r;
 					const unsigned long long m = maskw[par][row][wc] >> lr;
 					Top2 t{ninf, ninf, -1};
@@ -586,7 +979,7 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 
 	// merge the two item halves (wc) of every row, then decide
 	__syncthreads();
-	if (tid < kMU && i0 + tid < a.users) {
+	if (tid < kHU && i0 + tid < a.users) {
 		Top2 t{red_b1[tid][0], red_b2[tid][0], red_i1[tid][0]};
 		const Top2 o{red_b1[tid][1], red_b2[tid][1], red_i1[tid][1]};
 		top2_merge(t, o);

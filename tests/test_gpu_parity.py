@@ -435,12 +435,18 @@ def test_two_ranks_one_gpu_sharded_bench(capi):
     assert out["check"]["L_max_rel"] < 1e-9 and out["check"]["R_max_rel"] < 1e-9, out["check"]
 
 
-@pytest.mark.parametrize("impl", ["mfma", "exact"])
+@pytest.mark.parametrize("impl", ["mfma", "mfma-one-workgroup-per-cu", "mfma-two-per-cu-any-k", "exact"])
 def test_recommend_forms_agree_with_oracle(capi, orc, impl, monkeypatch):
-    """MFMA filter + exact certification vs the all-exact form vs the oracle, on shapes that cross every tile
-    edge (128-user blocks, 64-item tiles, K chunks of 16) and with planted exact ties."""
-    monkeypatch.setenv("MF_RECOMMEND_IMPL", impl)
-    for seed, (u, i, k) in enumerate([(1, 1, 1), (129, 65, 17), (300, 200, 100), (257, 130, 33), (64, 1000, 4)]):
+    """MFMA filter + exact certification (64-user workgroups two per CU where K allows, and the 128-user form alone) vs
+    the all-exact form vs the oracle, on shapes that cross every tile edge (64- and 128-user blocks, 64-item tile
+    halves, K chunks of 8 / 16 / 20) and with planted exact ties."""
+    monkeypatch.setenv("MF_RECOMMEND_IMPL", "exact" if impl == "exact" else "mfma")
+    if impl == "mfma-one-workgroup-per-cu":
+        monkeypatch.setenv("MF_RECOMMEND_HALF", "0")
+    if impl == "mfma-two-per-cu-any-k":
+        monkeypatch.setenv("MF_RECOMMEND_HALF", "all")   # the general form of recommend_mfma2_kernel (any even K <= 100)
+    for seed, (u, i, k) in enumerate([(1, 1, 1), (129, 65, 17), (300, 200, 100), (257, 130, 33), (64, 1000, 4), (65, 129, 2),
+                                      (200, 385, 30), (130, 700, 98), (193, 256, 6), (150, 300, 40), (70, 513, 60)]):
         rng = np.random.default_rng(40 + seed)
         L = rng.standard_normal((u, k))
         R = rng.standard_normal((i, k))
@@ -457,7 +463,7 @@ def test_recommend_forms_agree_with_oracle(capi, orc, impl, monkeypatch):
         assert info == -1 if impl == "exact" else info >= 0
 
 
-@pytest.mark.parametrize("k", [20, 48, 64, 66, 70, 72, 80, 90, 96, 98, 100, 104, 128])
+@pytest.mark.parametrize("k", [20, 40, 48, 60, 64, 66, 70, 72, 80, 90, 96, 98, 100, 104, 128])
 def test_recommend_every_chunk_depth_and_staging_form(capi, orc, k, monkeypatch):
     """The MFMA pass picks its chunk depth (32 / 24 / 20), resident-L image and LDS-DMA staging from K: every
     combination, with partial last chunks (66, 70, 90, 98), against the oracle -- with and without the DMA form."""
@@ -468,17 +474,19 @@ def test_recommend_every_chunk_depth_and_staging_form(capi, orc, k, monkeypatch)
     R[i - 1] = R[0]
     d = random_instance(200 + k, u, i, k, density=0.2, full_rows=(7,))
     want = orc.recommend(orc.Instance(**d), L, R)
-    for bdma in ("1", "0"):
+    for bdma, half in (("1", "1"), ("1", "all"), ("1", "0"), ("0", "0")):   # the two-per-CU form exists with LDS-DMA staging only
         monkeypatch.setenv("MF_RECOMMEND_BDMA", bdma)
+        monkeypatch.setenv("MF_RECOMMEND_HALF", half)
         plan = capi.Plan(u, i, k, 0.0, d["row"], d["col"], d["val"])
         plan.upload(L, R)
         best = plan.recommend()
         plan.close()
-        assert np.array_equal(best, want), (k, bdma)
+        assert np.array_equal(best, want), (k, bdma, half)
 
 
+@pytest.mark.parametrize("half", ["1", "0"])
 @pytest.mark.parametrize("split", ["0", "2", "3", "7", None])
-def test_recommend_item_split_of_small_problems(capi, orc, split, monkeypatch):
+def test_recommend_item_split_of_small_problems(capi, orc, split, half, monkeypatch):
     """A small recommendation (few 128-user blocks) splits the ITEMS over gridDim.y and merges the per-split top-2 reports
     (merge_splits_kernel): every split count -- none, the plan's own choice, counts that do not divide the tiles --
     against the oracle, with planted duplicates (certified only by the exact pass, lowest index wins), a fully rated user,
@@ -500,6 +508,7 @@ def test_recommend_item_split_of_small_problems(capi, orc, split, monkeypatch):
     order = np.lexsort((col, row))
     row, col = np.ascontiguousarray(row[order]), np.ascontiguousarray(col[order])
     val = np.ones(len(row))
+    monkeypatch.setenv("MF_RECOMMEND_HALF", half)
     if split is None:
         monkeypatch.delenv("MF_RECOMMEND_SPLIT", raising=False)
     else:

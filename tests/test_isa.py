@@ -183,6 +183,44 @@ def test_recommendation_runs_on_the_fp64_matrix_cores(kernels):
     assert not [i for i in kernels["mf::recommend_kernel(mf::RecArgs)"] if i.startswith("v_mfma")]
 
 
+def test_two_per_cu_recommend_keeps_its_matrix_stream_gapless(kernels, meta):
+    """recommend_mfma2_kernel<NC> (K = 20 NC): 40 NC matrix instructions per tile, the L operand in registers (no spill,
+    at most 256 VGPRs so that two workgroups share a CU), R fragments by ds_read2st64_b64 with immediate offsets only --
+    at most one vector add per chunk in the whole k-loop -- , a cheap reject of exactly 32 compares whose lane masks go to
+    scalar registers, every fragment read issued IN FRONT of the matrix instructions of the k-step before its own (the
+    scheduler sinks them otherwise), R chunks by LDS-DMA with a scalar base, M0 written in front of each."""
+    for nc in (1, 2, 3, 4, 5):
+        name = "void mf::recommend_mfma2_kernel<%d>(mf::RecMfmaArgs)" % nc
+        body, m = kernels[name], meta[name]
+        assert m[".vgpr_count"] <= 256 and m[".vgpr_spill_count"] == 0 and m[".private_segment_fixed_size"] == 0, m
+        assert m[".group_segment_fixed_size"] + 3 * 20480 <= 80 * 1024        # two workgroups per CU by LDS
+        mf = [i for i, x in enumerate(body) if x.startswith("v_mfma_f64_16x16x4")]
+        assert len(mf) == 40 * nc, (nc, len(mf))
+        assert sum(1 for x in body[mf[0]:mf[0] + 8] if x.startswith("v_mfma") and x.rstrip().endswith(", 0")) >= 1   # C = 0, no zeroing
+        loop = body[mf[0]:mf[-1] + 1]
+        assert not [x for x in loop if x.startswith(("ds_read_b64", "ds_read2_b64 "))], nc
+        assert 10 * nc - 2 <= sum(1 for x in loop if x.startswith("ds_read2st64_b64")) <= 10 * nc   # the first fragment of a tile is read under the tile before
+        valu = [x for x in loop if x.startswith("v_") and not x.startswith("v_mfma")]
+        # per chunk one base-address add; the out-of-line transfer issue holds none (scalar base, per-tile row offset)
+        assert len(valu) <= 2 * nc + 12, (nc, valu)
+        for pos, x in enumerate(body):
+            if x.startswith("global_load_lds_dwordx4"):
+                assert re.search(r", s\[\d+:\d+\]", x), x
+                assert body[pos - 1].startswith("s_nop") and body[pos - 2].startswith("s_mov_b32 m0,"), body[pos - 3:pos + 1]
+        tail = body[mf[-1] + 1:]
+        tail = tail[:next(i for i, x in enumerate(tail) if x.startswith("s_cbranch"))]   # up to the branch on "norms rule out non-finite scores"
+        assert [x.split()[0] for x in tail if x.startswith("v_")] == ["v_cmp_nle_f64_e32", "v_cmp_nle_f64_e64", "v_cmp_nle_f64_e32", "v_cmp_nle_f64_e32"] * 8, tail
+    # k-steps 2.. of every chunk: the two reads of the NEXT fragment stand before the first matrix instruction of the step
+    body = kernels["void mf::recommend_mfma2_kernel<5>(mf::RecMfmaArgs)"]
+    mf = [i for i, x in enumerate(body) if x.startswith("v_mfma_f64_16x16x4")]
+    groups = [mf[g:g + 8] for g in range(0, len(mf), 8)]
+    ahead = 0
+    for g, nxt in zip(groups, groups[1:]):
+        reads = [i for i in range(g[0] - 12, nxt[0]) if body[i].startswith("ds_read2st64_b64")]
+        ahead += sum(1 for i in reads if i < g[-1])
+    assert ahead >= 2 * (len(groups) - 1) - 4, ahead
+
+
 def test_sweeps_gather_by_lds_dma(kernels):
     """every LDS-DMA form of the sweep moves its rows with global_load_lds_dwordx4 (no VGPR staging, no ds_write of the tile)"""
     n = 0
