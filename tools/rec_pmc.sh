@@ -9,7 +9,7 @@ import csv, glob
 tot = {}
 for f in glob.glob("$O/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "recommend_mfma_kernel" in r["Kernel_Name"]:
+        if "recommend_mfma" in r["Kernel_Name"]:
             tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
             tot["_ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); tot["_name"] = r["Kernel_Name"]
 print("#", tot.pop("_name"), "kernel %.3f ms" % (tot.pop("_ns") / 1e6))
