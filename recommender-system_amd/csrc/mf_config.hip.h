@@ -54,6 +54,7 @@ struct mf_config {
 	int db_rows = 0;                  // MF_SWEEP_DB_ROWS: row count below which the double-buffered sweep is chosen (0: rule)
 	int sweep_long_kind[2] = {0, 0};  // MF_SWEEP_LONG_I / MF_SWEEP_LONG_U: the extreme-row threshold of the item / user sweep alone
 	int side_prio = -1;               // MF_SIDE_PRIO=0|1: the side stream of the extreme-row path at low / high priority (-1: rule)
+	bool rec_wide = false;            // MF_RECOMMEND_WIDE: K=128 in the eight-wave, 16-users-per-wave shape of K=256
 	int pf_rows = 0;                  // MF_SWEEP_PF_ROWS: launches of up to this many rows take the pipelined-phases form (0: 262144)
 	int pair_loaders = 0;             // MF_SWEEP_PAIR_LOADERS=1|2: loader waves of the wave-pair form (0: rule)
 	int pair_nch = 0;                 // MF_SWEEP_PAIR_NCH: chunk size of the wave-pair form (0: 32)
@@ -114,6 +115,7 @@ struct mf_config {
 		if ((v = getenv("MF_SWEEP_PAIR_NCH"))) c.pair_nch = atoi(v);
 		if ((v = getenv("MF_SWEEP_PAIR_LOADERS"))) c.pair_loaders = atoi(v);
 		if ((v = getenv("MF_SWEEP_PF_ROWS"))) c.pf_rows = atoi(v);
+		c.rec_wide = getenv("MF_RECOMMEND_WIDE") != nullptr;
 		if ((v = getenv("MF_SWEEP_LONG_I"))) c.sweep_long_kind[0] = atoi(v);
 		if ((v = getenv("MF_SWEEP_LONG_U"))) c.sweep_long_kind[1] = atoi(v);
 		if ((v = getenv("MF_SIDE_PRIO"))) c.side_prio = is0(v) ? 0 : 1;
@@ -168,6 +170,7 @@ struct mf_config {
 		if (pair_nch) add("MF_SWEEP_PAIR_NCH", std::to_string(pair_nch));
 		if (pair_loaders) add("MF_SWEEP_PAIR_LOADERS", std::to_string(pair_loaders));
 		if (pf_rows) add("MF_SWEEP_PF_ROWS", std::to_string(pf_rows));
+		if (rec_wide) add("MF_RECOMMEND_WIDE", "1");
 		if (sweep_long_kind[0]) add("MF_SWEEP_LONG_I", std::to_string(sweep_long_kind[0]));
 		if (sweep_long_kind[1]) add("MF_SWEEP_LONG_U", std::to_string(sweep_long_kind[1]));
 		if (side_prio >= 0) add("MF_SIDE_PRIO", std::to_string(side_prio));

@@ -511,16 +511,46 @@ static int launch_recommend_pass1(mf_plan *p, mf_filter *filt)
 	// per wave.  K=100: 64.7 vs 57.6 TFLOP/s on the 131072 x 100000 probe, K=80 64.3 vs 57.4, K=40 57.7 vs 52.1, K=20 49.7 vs
 	// 45.0.  Its general form (any even K <= 100, MF_RECOMMEND_HALF=all) has branches on K in the tile body that defeat
 	// hipcc's s_waitcnt placement and is slower than the 128-user kernel (K=64: 51.7 vs 58.5): not chosen by the rule.
-	const bool half = vec && allow_dma && p->cfg.rec_half && p->K <= mf::kHKmax && (p->K % mf::kHKC == 0 || p->cfg.rec_half == 2) &&
-	                  (unsigned long long) p->items * (unsigned long long) p->ldr * 8ull < (1ull << 32);   // 32-bit row offsets
+	// The same kernel with 16-deep chunks for K = 16, 32, .. 128 (two per CU as well) and, for K = 256, with 16 users per
+	// wave and eight waves per workgroup (one per CU): DESIGN.md 5.8.
+	const bool fits32 = (unsigned long long) p->items * (unsigned long long) p->ldr * 8ull < (1ull << 32);   // 32-bit row offsets
+	RecFn hfn = nullptr;
+	int hqc = 0, hwaves = 4;
+	if (vec && allow_dma && p->cfg.rec_half && fits32) {
+		const int K = p->K;
+		if (K % 20 == 0 && K <= mf::kHKmax) {
+			static const RecFn f20[5] = {mf::recommend_mfma2_kernel<1>, mf::recommend_mfma2_kernel<2>, mf::recommend_mfma2_kernel<3>,
+			                             mf::recommend_mfma2_kernel<4>, mf::recommend_mfma2_kernel<5>};
+			hfn = f20[K / 20 - 1];
+			hqc = 5;
+		} else if (K % 16 == 0 && K <= 128) {
+			static const RecFn f16[8] = {mf::recommend_mfma2_kernel<1, 4>, mf::recommend_mfma2_kernel<2, 4>, mf::recommend_mfma2_kernel<3, 4>,
+			                             mf::recommend_mfma2_kernel<4, 4>, mf::recommend_mfma2_kernel<5, 4>, mf::recommend_mfma2_kernel<6, 4>,
+			                             mf::recommend_mfma2_kernel<7, 4>, mf::recommend_mfma2_kernel<8, 4>};
+			hfn = f16[K / 16 - 1];
+			hqc = 4;
+		} else if (K == 256) {
+			hfn = mf::recommend_mfma2_kernel<8, 8, 1, 8>;
+			hqc = 8;
+			hwaves = 8;
+		}
+		if (K == 128 && p->cfg.rec_wide) {   // MF_RECOMMEND_WIDE (experiments build): K=128 in the eight-wave shape of K=256
+			hfn = mf::recommend_mfma2_kernel<4, 8, 1, 8>;
+			hqc = 8;
+			hwaves = 8;
+		}
+		if (!hfn && p->cfg.rec_half == 2 && K <= mf::kHKmax) {
+			hfn = mf::recommend_mfma2_kernel<0>;
+			hqc = 5;
+		}
+	}
+	const bool half = hfn != nullptr;
 	int block_users = mf::kMU, threads = mf::kMThreads;
 	if (half) {
-		static const RecFn whole[6] = {mf::recommend_mfma2_kernel<0>, mf::recommend_mfma2_kernel<1>, mf::recommend_mfma2_kernel<2>,
-		                               mf::recommend_mfma2_kernel<3>, mf::recommend_mfma2_kernel<4>, mf::recommend_mfma2_kernel<5>};
-		fn = whole[p->K % mf::kHKC == 0 ? p->K / mf::kHKC : 0];
-		lds = mf::rec_mfma2_lds();
+		fn = hfn;
+		lds = mf::rec_mfma2_lds(hqc);
 		block_users = mf::kHU;
-		threads = mf::kHThreads;
+		threads = 64 * hwaves;
 	}
 	p->rec_half_used = half;
 	MF_HIP(raise_lds_limit((const void *) fn, lds));
@@ -528,7 +558,7 @@ static int launch_recommend_pass1(mf_plan *p, mf_filter *filt)
 	// workgroups on 256 CUs).  The items are then split over gridDim.y -- whole 128-item tiles, about two workgroups per
 	// CU in all (four of the half-size ones) -- and the per-split top-2 reports merged and certified by merge_splits_kernel.
 	const int ublocks = (p->uc + block_users - 1) / block_users, tiles = (p->items + mf::kMI - 1) / mf::kMI;
-	const int chip = half ? 1024 : 512;
+	const int chip = half && hwaves == 4 ? 1024 : 512;   // workgroups the chip holds at once, times two
 	int nsplit = 1;
 	if (p->cfg.rec_split != 0 && ublocks < chip * 3 / 8 && tiles >= 2) {
 		nsplit = p->cfg.rec_split > 0 ? p->cfg.rec_split : (chip + ublocks - 1) / ublocks;

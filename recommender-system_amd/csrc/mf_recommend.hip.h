@@ -689,16 +689,24 @@ __global__ void __launch_bounds__(kMThreads) recommend_mfma_kernel(RecMfmaArgs a
 // (64 users per pass instead of 128): 3.8 TB/s of L2 -> LDS at cfg4, HBM traffic unchanged (the workgroups of an XCD
 // walk R = 80 MB in step).  Masks, top-2 bookkeeping and certification are those of recommend_mfma_kernel.
 // ------------------------------------------------------------------------------------------------
-constexpr int kHU = 64, kHThreads = 256, kHKC = 20, kHPC = kHKC / 2, kHQ = kHKC / 4, kHNB = 3, kHKmax = 100;
-constexpr int kHChunkD2 = kHPC * kMI;   // double2 elements of one R chunk image: [k-pair][128 items]
+constexpr int kHU = 64, kHNB = 3, kHKmax = 100;
 constexpr size_t kHStaticLds = 2 * kHU * 2 * 8 + kHU * 2 * (8 + 8 + 4 + 4) + 64;
-inline size_t rec_mfma2_lds() { return (size_t) kHNB * kHChunkD2 * sizeof(double2); }
+// dynamic LDS: the ring of kHNB chunks of QC k-steps (2 QC k-pairs x 128 items x 16 B each)
+inline size_t rec_mfma2_lds(int qc) { return (size_t) kHNB * (2 * qc) * kMI * sizeof(double2); }
 
 // NC > 0: K == 20 * NC exactly -- every chunk whole, no branch of the tile body depends on K (hipcc's s_waitcnt placement
 // follows the fragment pipeline only through straight-line code); NC == 0: any even K <= 100.
-template <int NC>
-__global__ void __launch_bounds__(kHThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) recommend_mfma2_kernel(RecMfmaArgs a)
+// The same kernel at other shapes: QC = k-steps per chunk (5: the 20-deep chunks above; 4 for K = 16 NC up to 128, two per
+// CU as well; 8 for K = 256), TU = 16-user tiles per wave, WAVES = 4 (two workgroups per CU) or 8.  K = 256 does not fit the
+// registers of a wave at 32 users (256 VGPRs for the L operand alone): there a wave owns 16 users x 64 items (TU = 1: 128
+// VGPRs of L, 32 accumulators, 4 matrix instructions per k-step) and EIGHT waves form the 64-user workgroup, one per CU --
+// the two waves of a SIMD then share their barriers, which costs little once each keeps the pipe full alone (ablation above).
+template <int NC, int QC = 5, int TU = 2, int WAVES = 4>
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) recommend_mfma2_kernel(RecMfmaArgs a)
 {
+	static_assert(16 * TU * (WAVES / 2) == kHU && (2 * QC) % (WAVES / 2) == 0 && (2 * QC) / (WAVES / 2) <= 5, "shape");
+	static_assert(NC > 0 || (QC == 5 && TU == 2 && WAVES == 4), "the general form exists for the 20-deep chunks only");
+	constexpr int kHThreads = 64 * WAVES, kHKC = 4 * QC, kHPC = 2 * QC, kHQ = QC, kHChunkD2 = kHPC * kMI;
 	constexpr int NCH = NC ? NC : kHKmax / kHKC, KSTEPS = NCH * kHQ;
 	extern __shared__ double2 rec_lds[];   // ring of kHNB R chunks: [k-pair][128 items]
 	const int K = a.K;
@@ -722,9 +730,9 @@ __global__ void __launch_bounds__(kHThreads) __attribute__((amdgpu_waves_per_eu(
 		nextcol = cur < cend ? a.csr_idx[cur] : INT32_MAX;
 		nextcol2 = cur + 1 < cend ? a.csr_idx[cur + 1] : INT32_MAX;
 	}
-	double thr2[8];   // runner-up of each of the lane's 8 rows: row(tu, r) = 32*wr + 16*tu + lq + 4*r
+	double thr2[4 * TU];   // runner-up of each of the lane's rows: row(tu, r) = 16*TU*wr + 16*tu + lq + 4*r
 #pragma unroll
-	for (int x = 0; x < 8; ++x) thr2[x] = ninf;
+	for (int x = 0; x < 4 * TU; ++x) thr2[x] = ninf;
 	if (tid < kHU) {
 #pragma unroll
 		for (int h = 0; h < 2; ++h) {
@@ -743,12 +751,12 @@ __global__ void __launch_bounds__(kHThreads) __attribute__((amdgpu_waves_per_eu(
 	// pairs beyond K are never transferred: the ring holds zeros there at first, not NaN patterns
 	for (int sl = tid; sl < kHNB * kHChunkD2; sl += kHThreads) rec_lds[sl] = make_double2(0.0, 0.0);
 	// the wave's L operand, once: k-step ks, user tile tu -> A[32*wr + 16*tu + lr][4*ks + lq] (zero beyond K / the last user)
-	double fa[KSTEPS][2];
+	double fa[KSTEPS][TU];
 #pragma unroll
 	for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
-		for (int tu = 0; tu < 2; ++tu) {
-			const int row = i0 + 32 * wr + 16 * tu + lr, k = 4 * ks + lq;
+		for (int tu = 0; tu < TU; ++tu) {
+			const int row = i0 + 16 * TU * wr + 16 * tu + lr, k = 4 * ks + lq;
 			fa[ks][tu] = row < a.users && k < K ? a.L[(size_t) row * a.ldl + k] : 0.0;
 		}
 	__syncthreads();
@@ -768,8 +776,8 @@ __global__ void __launch_bounds__(kHThreads) __attribute__((amdgpu_waves_per_eu(
 	auto dma_chunk = [&](int kc, int slot) -> int {
 		int n = 0;
 #pragma unroll
-		for (int h = 0; h < kHPC / 2; ++h) {
-			const int pr = wr + 2 * h, k = kc + 2 * pr;
+		for (int h = 0; h < kHPC / (WAVES / 2); ++h) {
+			const int pr = wr + (WAVES / 2) * h, k = kc + 2 * pr;
 			if (k < K) {   // wave-uniform
 				const char *sbase = reinterpret_cast<const char *>(a.R + k);
 				const unsigned m0 = bs_lds + (unsigned) ((slot * kHChunkD2 + pr * kMI + 64 * wc) * 16);
@@ -834,7 +842,7 @@ __global__ void __launch_bounds__(kHThreads) __attribute__((amdgpu_waves_per_eu(
 	frag(0, 0, fc);
 	int slot = 0, pending = 0;   // pending: this wave's transfers issued AFTER those of the chunk the next barrier publishes
 	for (int j0 = j_first; j0 < j_end; j0 += kMI) {
-		mf_d4 acc[2][4];
+		mf_d4 acc[TU][4];
 
 		// rated-item mask of this tile into the parity's copy; published by the chunk barriers below, and the other
 		// parity is not rewritten before every wave has passed them again (recommend_mfma_kernel)
@@ -886,7 +894,7 @@ __global__ void __launch_bounds__(kHThreads) __attribute__((amdgpu_waves_per_eu(
 						// use of the current fragment's registers to save eight VGPRs -- and expose the LDS latency per k-step)
 						__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-						for (int tu = 0; tu < 2; ++tu)
+						for (int tu = 0; tu < TU; ++tu)
 #pragma unroll
 							for (int ti = 0; ti < 4; ++ti)
 								acc[tu][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[c * kHQ + q][tu], fc[ti],
@@ -910,10 +918,10 @@ __global__ void __launch_bounds__(kHThreads) __attribute__((amdgpu_waves_per_eu(
 		// more instructions per row.  (!(v <= thr) is also true for a NaN.)  Only when the norms do not rule out non-finite
 		// scores a sum per row is formed as well: it is non-finite whenever a score is NaN or +-inf.
 		constexpr int kUGT = 10;   // llvm::FCmpInst::FCMP_UGT: unordered or greater than
-		unsigned long long rowm[8];
+		unsigned long long rowm[4 * TU];
 		unsigned long long anym = 0;
 #pragma unroll
-		for (int tu = 0; tu < 2; ++tu)
+		for (int tu = 0; tu < TU; ++tu)
 #pragma unroll
 			for (int r = 0; r < 4; ++r) {
 				const int x = tu * 4 + r;
@@ -923,7 +931,7 @@ __global__ void __launch_bounds__(kHThreads) __attribute__((amdgpu_waves_per_eu(
 			}
 		if (!all_finite) {
 #pragma unroll
-			for (int tu = 0; tu < 2; ++tu)
+			for (int tu = 0; tu < TU; ++tu)
 #pragma unroll
 				for (int r = 0; r < 4; ++r) {
 					const double sum = (acc[tu][0][r] + acc[tu][1][r]) + (acc[tu][2][r] + acc[tu][3][r]);
@@ -936,13 +944,13 @@ __global__ void __launch_bounds__(kHThreads) __attribute__((amdgpu_waves_per_eu(
 #endif
 		if (anym != 0)
 #pragma unroll
-		for (int tu = 0; tu < 2; ++tu)
+		for (int tu = 0; tu < TU; ++tu)
 #pragma unroll
 			for (int r = 0; r < 4; ++r) {
 				const int x = tu * 4 + r;
 				// slow path exactly as in recommend_mfma_kernel
 				if (rowm[x] != 0) {
-					const int row = 32 * wr + 16 * tu + lq + 4 * r;
+					const int row = 16 * TU * wr + 16 * tu + lq + 4 * r;
 					const unsigned long long m = maskw[par][row][wc] >> lr;
 					Top2 t{ninf, ninf, -1};
 					int bd = 0;

@@ -463,7 +463,7 @@ def test_recommend_forms_agree_with_oracle(capi, orc, impl, monkeypatch):
         assert info == -1 if impl == "exact" else info >= 0
 
 
-@pytest.mark.parametrize("k", [20, 40, 48, 60, 64, 66, 70, 72, 80, 90, 96, 98, 100, 104, 128])
+@pytest.mark.parametrize("k", [16, 20, 32, 40, 48, 60, 64, 66, 70, 72, 80, 90, 96, 98, 100, 104, 112, 128, 256])
 def test_recommend_every_chunk_depth_and_staging_form(capi, orc, k, monkeypatch):
     """The MFMA pass picks its chunk depth (32 / 24 / 20), resident-L image and LDS-DMA staging from K: every
     combination, with partial last chunks (66, 70, 90, 98), against the oracle -- with and without the DMA form."""

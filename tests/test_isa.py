@@ -162,16 +162,21 @@ def test_hand_counted_vmcnt_of_the_ordered_sums(kernels):
 
 
 def test_timed_path_kernels_do_not_spill(kernels, meta):
-    # generic fallbacks that may touch scratch: the odd-K matrix-core form staged through registers
-    allowed = {"void mf::recommend_mfma_kernel<false, 32, false, false>(mf::RecMfmaArgs)"}
+    # K = 128 at two workgroups per CU sits at the 256-register limit (128 VGPRs of L operand, 64 accumulators): hipcc parks
+    # ONE value of the prologue in scratch and fetches it after the last tile -- nothing between the first and the last
+    # matrix instruction may touch scratch (a scratch access inside the loop would also join the hand-counted vmcnt)
+    allowed = {"void mf::recommend_mfma2_kernel<8, 4, 2, 4>(mf::RecMfmaArgs)": 16}
     for name, body in kernels.items():
-        if "mf::" not in name or name in allowed:
+        if "mf::" not in name:
+            continue
+        m = meta[name]
+        if name in allowed:
+            mf = [i for i, x in enumerate(body) if x.startswith("v_mfma")]
+            assert not [x for x in body[mf[0]:mf[-1] + 1] if x.startswith("scratch_")], name
+            assert m[".private_segment_fixed_size"] <= allowed[name] and m[".vgpr_spill_count"] <= 2, (name, m)
             continue
         assert not [i for i in body if i.startswith("scratch_")], name
-        m = meta[name]
         assert m[".private_segment_fixed_size"] == 0 and m[".vgpr_spill_count"] == 0, (name, m)
-    for name in allowed:
-        assert meta[name][".private_segment_fixed_size"] <= 64, meta[name]
 
 
 def test_recommendation_runs_on_the_fp64_matrix_cores(kernels):
@@ -184,34 +189,36 @@ def test_recommendation_runs_on_the_fp64_matrix_cores(kernels):
 
 
 def test_two_per_cu_recommend_keeps_its_matrix_stream_gapless(kernels, meta):
-    """recommend_mfma2_kernel<NC> (K = 20 NC): 40 NC matrix instructions per tile, the L operand in registers (no spill,
+    """recommend_mfma2_kernel<NC, QC, TU, WAVES> (K = 4 QC NC): 4 TU QC NC matrix instructions per tile, the L operand in registers (no spill,
     at most 256 VGPRs so that two workgroups share a CU), R fragments by ds_read2st64_b64 with immediate offsets only --
     at most one vector add per chunk in the whole k-loop -- , a cheap reject of exactly 32 compares whose lane masks go to
     scalar registers, every fragment read issued IN FRONT of the matrix instructions of the k-step before its own (the
     scheduler sinks them otherwise), R chunks by LDS-DMA with a scalar base, M0 written in front of each."""
-    for nc in (1, 2, 3, 4, 5):
-        name = "void mf::recommend_mfma2_kernel<%d>(mf::RecMfmaArgs)" % nc
+    shapes = [(nc, 5, 2, 4) for nc in (1, 2, 3, 4, 5)] + [(nc, 4, 2, 4) for nc in (1, 2, 3, 4, 5, 6, 7, 8)] + [(8, 8, 1, 8)]   # K = 20 NC, 16 NC, 256
+    for nc, qc, tu, waves in shapes:
+        name = "void mf::recommend_mfma2_kernel<%d, %d, %d, %d>(mf::RecMfmaArgs)" % (nc, qc, tu, waves)
         body, m = kernels[name], meta[name]
-        assert m[".vgpr_count"] <= 256 and m[".vgpr_spill_count"] == 0 and m[".private_segment_fixed_size"] == 0, m
-        assert m[".group_segment_fixed_size"] + 3 * 20480 <= 80 * 1024        # two workgroups per CU by LDS
+        assert m[".vgpr_count"] <= 256 and m[".vgpr_spill_count"] <= (2 if (nc, qc) == (8, 4) else 0), (name, m)   # K=128: see the spill test
+        ring = 3 * 2 * qc * 128 * 16
+        assert m[".group_segment_fixed_size"] + ring <= (80 if waves == 4 else 160) * 1024        # two workgroups per CU by LDS (one of eight waves)
         mf = [i for i, x in enumerate(body) if x.startswith("v_mfma_f64_16x16x4")]
-        assert len(mf) == 40 * nc, (nc, len(mf))
-        assert sum(1 for x in body[mf[0]:mf[0] + 8] if x.startswith("v_mfma") and x.rstrip().endswith(", 0")) >= 1   # C = 0, no zeroing
+        assert len(mf) == 4 * tu * qc * nc, (name, len(mf))
+        assert sum(1 for x in body[mf[0]:mf[0] + 4 * tu] if x.startswith("v_mfma") and x.rstrip().endswith(", 0")) >= 1   # C = 0, no zeroing
         loop = body[mf[0]:mf[-1] + 1]
-        assert not [x for x in loop if x.startswith(("ds_read_b64", "ds_read2_b64 "))], nc
-        assert 10 * nc - 2 <= sum(1 for x in loop if x.startswith("ds_read2st64_b64")) <= 10 * nc   # the first fragment of a tile is read under the tile before
+        assert not [x for x in loop if x.startswith(("ds_read_b64", "ds_read2_b64 "))], name
+        assert 2 * qc * nc - 2 <= sum(1 for x in loop if x.startswith("ds_read2st64_b64")) <= 2 * qc * nc   # the first fragment of a tile is read under the tile before
         valu = [x for x in loop if x.startswith("v_") and not x.startswith("v_mfma")]
         # per chunk one base-address add; the out-of-line transfer issue holds none (scalar base, per-tile row offset)
-        assert len(valu) <= 2 * nc + 12, (nc, valu)
+        assert len(valu) <= 2 * nc + 12, (name, valu)
         for pos, x in enumerate(body):
             if x.startswith("global_load_lds_dwordx4"):
                 assert re.search(r", s\[\d+:\d+\]", x), x
                 assert body[pos - 1].startswith("s_nop") and body[pos - 2].startswith("s_mov_b32 m0,"), body[pos - 3:pos + 1]
         tail = body[mf[-1] + 1:]
         tail = tail[:next(i for i, x in enumerate(tail) if x.startswith("s_cbranch"))]   # up to the branch on "norms rule out non-finite scores"
-        assert [x.split()[0] for x in tail if x.startswith("v_")] == ["v_cmp_nle_f64_e32", "v_cmp_nle_f64_e64", "v_cmp_nle_f64_e32", "v_cmp_nle_f64_e32"] * 8, tail
+        assert [x.split()[0] for x in tail if x.startswith("v_")] == ["v_cmp_nle_f64_e32", "v_cmp_nle_f64_e64", "v_cmp_nle_f64_e32", "v_cmp_nle_f64_e32"] * (4 * tu), tail
     # k-steps 2.. of every chunk: the two reads of the NEXT fragment stand before the first matrix instruction of the step
-    body = kernels["void mf::recommend_mfma2_kernel<5>(mf::RecMfmaArgs)"]
+    body = kernels["void mf::recommend_mfma2_kernel<5, 5, 2, 4>(mf::RecMfmaArgs)"]
     mf = [i for i, x in enumerate(body) if x.startswith("v_mfma_f64_16x16x4")]
     groups = [mf[g:g + 8] for g in range(0, len(mf), 8)]
     ahead = 0
