@@ -691,6 +691,8 @@ int plan_es_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vector
 	{
 		const int sw = p->res_sw, nsl = (p->K + sw - 1) / sw;
 		const int per = std::max(1, ncu / (2 * nsl));
+		// waves of a workgroup that own rows (the others only help with the slice copy): MF_ES_ACTIVE
+		const int aw = p->cfg.es_active >= 1 && p->cfg.es_active <= mf::kResidentWaves ? p->cfg.es_active : mf::kResidentWaves;
 		std::vector<mf::SliceWg> wgs;
 		for (int side = 0; side < 2; ++side) {
 			const std::vector<int> &pt = side == 0 ? cptr : rptr;
@@ -700,7 +702,7 @@ int plan_es_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vector
 			// workgroups than one per CU and slice
 			std::vector<int> cut(1, 0);
 			{
-				const int target_runs = per * mf::kResidentWaves;
+				const int target_runs = per * aw;
 				const double total_cost = (double) pt[(size_t) nrows] + 16.0 * nrows;
 				double acc_cost = 0, done = 0;
 				int in_run = 0;
@@ -717,16 +719,16 @@ int plan_es_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vector
 					}
 				}
 				cut.push_back(nrows);
-				while (((int) cut.size() - 1) % mf::kResidentWaves != 0) cut.push_back(nrows);
+				while (((int) cut.size() - 1) % aw != 0) cut.push_back(nrows);
 			}
-			const int nwg_side = ((int) cut.size() - 1) / mf::kResidentWaves;
+			const int nwg_side = ((int) cut.size() - 1) / aw;
 			for (int sl = 0; sl < nsl; ++sl)
 				for (int w = 0; w < nwg_side; ++w) {
 					mf::SliceWg g;
 					g.side = side;
 					g.slice = sl;
 					for (int i = 0; i <= mf::kResidentWaves; ++i) {
-						g.row_beg[i] = cut[(size_t) (w * mf::kResidentWaves + i)];
+						g.row_beg[i] = cut[(size_t) (w * aw + std::min(i, aw))];
 						g.ent_beg[i] = pt[(size_t) g.row_beg[i]];
 					}
 					if (g.row_beg[mf::kResidentWaves] > g.row_beg[0]) wgs.push_back(g);

@@ -50,6 +50,7 @@ struct mf_config {
 	bool no_defer = false;            // MF_SWEEP_NO_DEFER
 	bool nosort = false;              // MF_SWEEP_NOSORT
 	bool rest_coop = false;           // MF_SWEEP_REST=coop
+	int es_active = 0;                // MF_ES_ACTIVE=1..8: waves per workgroup of the streams launch that own rows (0: rule)
 	int es_nch = 0;                   // MF_ES_NCH: segment size of the errors launch
 	int db_rows = 0;                  // MF_SWEEP_DB_ROWS: row count below which the double-buffered sweep is chosen (0: rule)
 	int sweep_long_kind[2] = {0, 0};  // MF_SWEEP_LONG_I / MF_SWEEP_LONG_U: the extreme-row threshold of the item / user sweep alone
@@ -110,6 +111,7 @@ struct mf_config {
 		c.nosort = getenv("MF_SWEEP_NOSORT") != nullptr;
 		c.rest_coop = eq(getenv("MF_SWEEP_REST"), "coop");
 		if ((v = getenv("MF_ES_NCH"))) c.es_nch = atoi(v);
+		if ((v = getenv("MF_ES_ACTIVE"))) c.es_active = atoi(v);
 		if ((v = getenv("MF_SWEEP_DB_ROWS"))) c.db_rows = atoi(v);
 		if ((v = getenv("MF_SWEEP_DB_NCH"))) c.db_nch = atoi(v);
 		if ((v = getenv("MF_SWEEP_PAIR_NCH"))) c.pair_nch = atoi(v);
@@ -165,6 +167,7 @@ struct mf_config {
 		if (nosort) add("MF_SWEEP_NOSORT", "1");
 		if (rest_coop) add("MF_SWEEP_REST", "coop");
 		if (es_nch) add("MF_ES_NCH", std::to_string(es_nch));
+		if (es_active) add("MF_ES_ACTIVE", std::to_string(es_active));
 		if (db_rows) add("MF_SWEEP_DB_ROWS", std::to_string(db_rows));
 		if (db_nch) add("MF_SWEEP_DB_NCH", std::to_string(db_nch));
 		if (pair_nch) add("MF_SWEEP_PAIR_NCH", std::to_string(pair_nch));

@@ -913,6 +913,14 @@ int mf_debug_read_stamps(unsigned long long *out8)
 	return MF_OK;
 }
 
+// per-wave clocks of the streams launch of the errors + streams iteration (tools/es_stamps.py)
+int mf_debug_read_es_stamps(unsigned long long *out, int words)
+{
+	MF_HIP(hipDeviceSynchronize());
+	MF_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(mf::mf_es_stamp_buf), sizeof(unsigned long long) * (size_t) words));
+	return MF_OK;
+}
+
 // the same for recommend_mfma_kernel (tools/rec_stamps.py): waves 0 and 7 of workgroup 0
 int mf_debug_read_rec_stamps(unsigned long long *out32)
 {

@@ -45,9 +45,19 @@ struct SliceArgs {
 	int ldx[2], ldy[2];               // row pitch of X and of Y per side, in doubles (>= K)
 };
 
+#ifdef MF_STAMPS
+// diagnostic build only (tools/es_stamps.py): per workgroup and wave -- [0] s_memrealtime at entry (100 MHz), [1] shader
+// cycles until the slice is in LDS (after the barrier), [2] shader cycles until the wave's last row is stored, [3]
+// s_memrealtime at exit, [4] entries of the wave, [5] rows of the wave
+__device__ unsigned long long mf_es_stamp_buf[512 * kResidentWaves * 6];
+#endif
+
 template <int SW>
 __global__ void __launch_bounds__(kResidentThreads) stream_resident_kernel(SliceArgs a)
 {
+#ifdef MF_STAMPS
+	const unsigned long long st_real0 = __builtin_amdgcn_s_memrealtime(), st_clk0 = __builtin_amdgcn_s_memtime();
+#endif
 	static_assert(SW == 8 || SW == 4 || SW == 2, "slice width in columns");
 	constexpr int G = kWave / SW;          // entries per step = lane groups per wave
 	extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -111,6 +121,21 @@ __global__ void __launch_bounds__(kResidentThreads) stream_resident_kernel(Slice
 	recbuf[64 + lane] = StreamRec{0, 0, 0.0};   // padding behind the chunk (read three steps ahead, never used)
 	if (lane < 32) recbuf[128 + lane] = StreamRec{0, 0, 0.0};
 	__syncthreads();
+#ifdef MF_STAMPS
+	const unsigned long long st_clk1 = __builtin_amdgcn_s_memtime();
+	auto stamp_out = [&]() {
+		if (lane == 0 && blockIdx.x < 512) {
+			unsigned long long *o = mf_es_stamp_buf + ((size_t) blockIdx.x * kResidentWaves + wave) * 6;
+			o[0] = st_real0;
+			o[1] = st_clk1 - st_clk0;
+			o[2] = __builtin_amdgcn_s_memtime() - st_clk0;
+			o[3] = __builtin_amdgcn_s_memrealtime();
+			o[4] = (unsigned long long) (ee - eb);
+			o[5] = (unsigned long long) (re - rb);
+		}
+	};
+	if (rb >= re) stamp_out();
+#endif
 	if (rb >= re) return;
 
 	// ---- the stream.  cur = the row being added up, row_end = its last entry + 1, acc = its running sum.
@@ -233,6 +258,10 @@ __global__ void __launch_bounds__(kResidentThreads) stream_resident_kernel(Slice
 	// trailing rows without entries (and the last row when the stretch is empty)
 	row_end = ee;
 	close_rows_at(ee);
+#ifdef MF_STAMPS
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	stamp_out();
+#endif
 }
 
 }  // namespace mf

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""instML100k, streams launch of the errors + streams iteration: where its ~22 us go.  Per-wave clocks from the diagnostic
+build (make -C recommender-system_amd csrc/libmatfact_hip_stamps.so; MF_HIP_LIB pointing at it): s_memrealtime at entry and
+exit of every wave (100 MHz: the launch's own timeline), shader cycles until the Y slice is in LDS, until the last row."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import recommender_system_amd as rs
+c = rs.capi
+inst = c.parse_file(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "instML100k.in.gz"))
+L, R = c.init_factors(inst.users, inst.items, inst.feats)
+os.environ["MF_GRAPH"] = "0"
+plan = c.Plan(inst.users, inst.items, inst.feats, inst.alpha, inst.row, inst.col, inst.val)
+print(plan.describe())
+plan.upload(L, R)
+plan.iterate(50); plan.synchronize()
+lib = c.hip()
+NW = 512 * 8 * 6
+buf = (C.c_ulonglong * NW)()
+for rep in range(3):
+    plan.iterate(1); plan.synchronize()
+    lib.mf_debug_read_es_stamps(buf, NW)
+    a = np.array(buf[:], dtype=np.uint64).reshape(512, 8, 6).astype(np.float64)
+    used = a[:, :, 3] > 0
+    wg_used = used.any(axis=1)
+    t0 = a[:, :, 0][used].min()
+    ent = (a[:, :, 0] - t0) * 10.0 / 1e3          # us
+    ext = (a[:, :, 3] - t0) * 10.0 / 1e3
+    act = used & (a[:, :, 5] > 0)
+    print("rep %d: workgroups %d, waves with rows %d | entry of the waves: last at %.2f us | slice in LDS after %.0f cycles on average "
+          "(max %.0f) | stream (entry -> last store): average %.0f cycles, max %.0f | exit: average %.2f us, last %.2f us" % (
+              rep, wg_used.sum(), act.sum(), ent[used].max(), a[:, :, 1][act].mean(), a[:, :, 1][act].max(),
+              (a[:, :, 2] - a[:, :, 1])[act].mean(), (a[:, :, 2] - a[:, :, 1])[act].max(), ext[act].mean(), ext[act].max()))
+    # the slowest waves
+    dur = np.where(act, a[:, :, 2] - a[:, :, 1], 0)
+    order = np.dstack(np.unravel_index(np.argsort(-dur, axis=None), dur.shape))[0][:6]
+    for wg, w in order:
+        print("   wg %3d wave %d: entries %5d rows %3d  copy %6.0f cycles  stream %6.0f cycles = %.1f per entry  entry %.2f us exit %.2f us" % (
+            wg, w, a[wg, w, 4], a[wg, w, 5], a[wg, w, 1], dur[wg, w], dur[wg, w] / max(a[wg, w, 4], 1), ent[wg, w], ext[wg, w]))
+    cyc_per_entry = ((a[:, :, 2] - a[:, :, 1])[act] / np.maximum(a[:, :, 4][act], 1))
+    print("   cycles per entry over the waves: median %.1f, 10th-90th percentile %.1f-%.1f; entries per wave: mean %.0f max %.0f" % (
+        np.median(cyc_per_entry), np.percentile(cyc_per_entry, 10), np.percentile(cyc_per_entry, 90), a[:, :, 4][act].mean(), a[:, :, 4][act].max()))
+plan.close()
