@@ -376,19 +376,32 @@ int build_sparse(mf_plan *p, const mf_shard *s_in, const mf_entry *aos, bool swa
 }
 
 // Does the single-wave launch of this sweep take the wave-pair form (mf_sweep.hip.h: loader + compute wave per row)?  Where
-// the kernel exists (64 <= K <= 128, compile-time K) and the launch is small and skewed: at most 65536 rows, at most
-// ~2 ms of bytes, the longest row at least four times the mean -- such a launch ENDS on its long rows, which a pair walks
-// 2.4x faster than one wave.  A launch of equally long rows is faster on the single-wave form (cfg3 uniform 0.207 vs
-// 0.222 ms), and so is a large skewed one, bound by throughput rather than by its tail (the Netflix shape's item sweep,
-// 17770 rows of 3770 entries on average: 11.0 vs 14.3 ms).  MF_SWEEP_PAIR=0|1 overrides.
+// the kernel exists (64 <= K <= 128, compile-time K) and the launch is skewed -- the longest row at least four times the
+// mean -- and either
+//   small: at most 65536 rows and ~2 ms of bytes -- such a launch ENDS on its long rows, which a pair walks 2.4x faster than
+//          one wave (cfg3 power-law); or
+//   made of long rows: 512 entries per row or more on average (the Netflix shape's 17770 items of 3770 entries, cfg4-Zipf's
+//          1e5 items of 1000) -- with the pairs the extreme-row threshold moves up 2.7x (plan_row_schedule), the scratch round
+//          trip shrinks and the side stream no longer eats into the other sweep: Netflix shape 19.7 -> 17.1 ms, cfg4-Zipf
+//          35.5 -> 31.2 (tools/r3_pair_nflx.sh; at the single-wave threshold the pairs LOSE there, 20.0 vs 19.7).
+// A launch of equally long rows stays on the single-wave form (cfg3 uniform 0.207 vs 0.222 ms; cfg4's items 11.95 vs 12.24 ms
+// would gain 2 %, not taken), and so does a large one of short rows (users of the Netflix shape 8.2 vs 6.8 ms, of cfg4 12.9
+// vs 11.4).  MF_SWEEP_PAIR=0|1 overrides.
+static bool pair_long_rows(const mf_plan *p, int kind)
+{
+	const int nrows = kind == 0 ? p->items : p->uc;
+	return nrows >= 512 && p->nnz / nrows >= 512;
+}
 bool pair_wanted(const mf_plan *p, int kind)
 {
 	if (!p->sweep.pair || p->cfg.sweep_pair == 0) return false;
 	if (p->cfg.sweep_pair == 1) return true;
+	if (p->cfg.sweep_pair_kind[kind] >= 0) return p->cfg.sweep_pair_kind[kind] == 1;   // MF_SWEEP_PAIR_I / _U (experiments build)
 	const int nrows = kind == 0 ? p->items : p->uc;
-	if (nrows < 512 || nrows > 65536 || p->nnz <= 0) return false;
-	if ((double) p->nnz * 8.0 * p->K / 6e12 * 1e6 > 2000.0) return false;
-	return (long long) p->max_row_len[kind] >= 4 * std::max<long long>(p->nnz / nrows, 1);
+	if (nrows < 512 || p->nnz <= 0) return false;
+	if ((long long) p->max_row_len[kind] < 4 * std::max<long long>(p->nnz / nrows, 1)) return false;
+	const bool small = nrows <= 65536 && (double) p->nnz * 8.0 * p->K / 6e12 * 1e6 <= 2000.0;
+	return small || pair_long_rows(p, kind);
 }
 
 // Schedule of the two sweeps from the row lengths: which rows count as long, whether a tiny sweep runs as ONE
@@ -422,7 +435,12 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 			const int nrows = kind == 0 ? p->items : p->uc;
 			// ... and only rows well above the average count as long: when every row is equally long (the cfg4
 			// twin: 1000 items x 1000 entries) there is no skew to fix and the single-wave kernel is the faster one
-			const int t_kind = cfg.sweep_long_kind[kind] > 0 ? cfg.sweep_long_kind[kind] : cfg.sweep_long_set ? t_long : std::max(t_long, (int) std::min<long long>(4 * (long long) (p->nnz / std::max(nrows, 1)), 2000000000ll));
+			// (a side of long rows walked by wave pairs -- 0.055 us per entry instead of 0.13 --: 16e-6 nnz K.  Netflix shape,
+			// pairs on the item side: 18.5 / 17.9 / 17.1 / 18.6 ms at 60 / 80 / 100 / 160 thousand entries, the rule gives 107 000;
+			// cfg4-Zipf 32.6 / 31.2 / 31.2 / 39.9 at 120 / 160 / 220 / 400 thousand, the rule gives 160 000)
+			const bool pairs_long = pair_wanted(p, kind) && pair_long_rows(p, kind) && p->cfg.sweep_pair != 1;
+			const int t_side = pairs_long ? std::max(128, (int) std::min(16e-6 * (double) p->nnz * (double) p->K, 2e9)) : t_long;
+			const int t_kind = cfg.sweep_long_kind[kind] > 0 ? cfg.sweep_long_kind[kind] : cfg.sweep_long_set ? t_long : std::max(t_side, (int) std::min<long long>(4 * (long long) (p->nnz / std::max(nrows, 1)), 2000000000ll));
 			if (p->max_row_len[kind] < t_kind) continue;
 			// With the wave-pair form a long row is walked at ~0.055 us per entry at K=100 (a lone single wave: 0.13): when
 			// even the longest row's walk fits the sweep's bandwidth time the split buys nothing and costs the scratch
