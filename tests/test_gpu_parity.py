@@ -305,7 +305,8 @@ def test_switches_are_read_once_per_plan_and_experiments_are_not_in_the_shipped_
     later = capi.Plan(120, 90, 100, 0.01, d["row"], d["col"], d["val"])
     assert "config{MF_SWEEP_NCH=7}" in later.describe() and " nch=7 " in later.describe(), later.describe()
     monkeypatch.delenv("MF_SWEEP_NCH")
-    for k, v in (("MF_SWEEP_SEG", "32"), ("MF_SWEEP_PNCH", "8"), ("MF_ES_NCH", "8"), ("MF_SWEEP_FEW", "1"), ("MF_SWEEP_PF", "0")):
+    for k, v in (("MF_SWEEP_SEG", "32"), ("MF_SWEEP_PNCH", "8"), ("MF_ES_NCH", "8"), ("MF_SWEEP_FEW", "1"), ("MF_SWEEP_PF", "0"),
+                 ("MF_ES_ACTIVE", "4"), ("MF_SWEEP_PAIR_I", "1"), ("MF_SWEEP_PF_ROWS", "5"), ("MF_RECOMMEND_WIDE", "1")):
         monkeypatch.setenv(k, v)                        # experiments: not compiled into the shipped library
     exp = capi.Plan(120, 90, 100, 0.01, d["row"], d["col"], d["val"])
     assert exp.describe() == plain.describe(), (exp.describe(), plain.describe())
@@ -335,6 +336,35 @@ def test_dispatch_order_of_a_large_skewed_sweep(capi, orc):
     Lo, Ro = orc.init_factors(U, I, K)
     orc.factorize(orc.Instance(**d), Lo, Ro, iters=1)
     assert "long_rows=" in desc and np.array_equal(Lg, Lo) and np.array_equal(Rg, Ro), desc
+
+
+def test_wave_pairs_on_a_large_side_of_long_skewed_rows(capi, orc):
+    """The second case of pair_wanted (mf_build.hip.h): a side that is NOT small -- more than ~2 ms of bytes per sweep -- but
+    made of long, skewed rows (600 items of ~27 000 entries, one of them rated by nearly every user) takes the wave-pair
+    form, with that side's extreme-row threshold at 16e-6 nnz K; the users (133 entries on average) stay on single waves.
+    One iteration of 1.6e7 entries, bit-exact against the oracle."""
+    U, I, K = 120000, 600, 100
+    rng = np.random.default_rng(2025)
+    lens = rng.integers(20000, 33001, I)
+    lens[7] = 118000                                    # the hot item: above 4x the mean and above the threshold
+    lens[300] = 90000                                   # long, but walked by a pair (below 4x the mean)
+    col = np.repeat(np.arange(I, dtype=np.int32), lens)
+    row = np.concatenate([rng.choice(U, int(n), replace=False) for n in lens]).astype(np.int32)
+    order = np.lexsort((col, row))
+    row, col = np.ascontiguousarray(row[order]), np.ascontiguousarray(col[order])
+    val = rng.integers(1, 6, len(row)).astype(np.float64)
+    d = dict(iters=1, alpha=1e-6, feats=K, users=U, items=I, row=row, col=col, val=val)
+    plan = capi.Plan(U, I, K, d["alpha"], row, col, val)
+    desc = plan.describe()
+    L, R = capi.init_factors(U, I, K)
+    plan.upload(L, R)
+    plan.iterate(1)
+    Lg, Rg = plan.download()
+    plan.close()
+    assert "long_rows=1/0" in desc and ("wave_pair=1/0" in desc or "MF_SWEEP_DB=1" in desc), desc   # (the forced double-buffered form replaces the pairs)
+    Lo, Ro = orc.init_factors(U, I, K)
+    orc.factorize(orc.Instance(**d), Lo, Ro, iters=1)
+    assert np.array_equal(Lg, Lo) and np.array_equal(Rg, Ro), desc
 
 
 def test_plan_sharded_sweeps_match_oracle_shard_step(capi, orc):
