@@ -376,17 +376,18 @@ int build_sparse(mf_plan *p, const mf_shard *s_in, const mf_entry *aos, bool swa
 }
 
 // Does the single-wave launch of this sweep take the wave-pair form (mf_sweep.hip.h: loader + compute wave per row)?  Where
-// the kernel exists (64 <= K <= 128, compile-time K) and the launch is skewed -- the longest row at least four times the
-// mean -- and either
-//   small: at most 65536 rows and ~2 ms of bytes -- such a launch ENDS on its long rows, which a pair walks 2.4x faster than
-//          one wave (cfg3 power-law); or
-//   made of long rows: 512 entries per row or more on average (the Netflix shape's 17770 items of 3770 entries, cfg4-Zipf's
-//          1e5 items of 1000) -- with the pairs the extreme-row threshold moves up 2.7x (plan_row_schedule), the scratch round
-//          trip shrinks and the side stream no longer eats into the other sweep: Netflix shape 19.7 -> 17.1 ms, cfg4-Zipf
-//          35.5 -> 31.2 (tools/r3_pair_nflx.sh; at the single-wave threshold the pairs LOSE there, 20.0 vs 19.7).
-// A launch of equally long rows stays on the single-wave form (cfg3 uniform 0.207 vs 0.222 ms; cfg4's items 11.95 vs 12.24 ms
-// would gain 2 %, not taken), and so does a large one of short rows (users of the Netflix shape 8.2 vs 6.8 ms, of cfg4 12.9
-// vs 11.4).  MF_SWEEP_PAIR=0|1 overrides.
+// the kernel exists (64 <= K <= 128, compile-time K) and the side is
+//   made of long rows: 512 entries per row or more on average, skewed or not -- a wave spends its life inside rows, where
+//          the pair overlaps the gather of chunk c+1 with the arithmetic of chunk c (cfg4's 1e5 items of 1000 entries:
+//          11.77 vs 12.19 ms, three alternating runs on one box).  On a skewed side of that kind (the Netflix shape's 17770
+//          items of 3770 entries, cfg4-Zipf's) the extreme-row threshold moves up 2.7x with the pairs (plan_row_schedule),
+//          the scratch round trip shrinks and the side stream no longer eats into the other sweep: Netflix shape 19.7 ->
+//          17.1 ms, cfg4-Zipf 35.5 -> 31.2 (tools/r3_pair_nflx.sh; at the single-wave threshold the pairs LOSE there, 20.0
+//          vs 19.7); or
+//   small and skewed: at most 65536 rows and ~2 ms of bytes, the longest row at least four times the mean -- such a launch
+//          ENDS on its long rows, which a pair walks 2.4x faster than one wave (cfg3 power-law).
+// Short equally long rows stay on the single-wave form (cfg3 uniform, 253 / 166 entries per row: 0.207 vs 0.222 ms), and so
+// does a large side of short rows (users of the Netflix shape 8.2 vs 6.8 ms, of cfg4 12.9 vs 11.4).  MF_SWEEP_PAIR=0|1 overrides.
 static bool pair_long_rows(const mf_plan *p, int kind)
 {
 	const int nrows = kind == 0 ? p->items : p->uc;
@@ -399,9 +400,9 @@ bool pair_wanted(const mf_plan *p, int kind)
 	if (p->cfg.sweep_pair_kind[kind] >= 0) return p->cfg.sweep_pair_kind[kind] == 1;   // MF_SWEEP_PAIR_I / _U (experiments build)
 	const int nrows = kind == 0 ? p->items : p->uc;
 	if (nrows < 512 || p->nnz <= 0) return false;
+	if (pair_long_rows(p, kind)) return true;
 	if ((long long) p->max_row_len[kind] < 4 * std::max<long long>(p->nnz / nrows, 1)) return false;
-	const bool small = nrows <= 65536 && (double) p->nnz * 8.0 * p->K / 6e12 * 1e6 <= 2000.0;
-	return small || pair_long_rows(p, kind);
+	return nrows <= 65536 && (double) p->nnz * 8.0 * p->K / 6e12 * 1e6 <= 2000.0;
 }
 
 // Schedule of the two sweeps from the row lengths: which rows count as long, whether a tiny sweep runs as ONE

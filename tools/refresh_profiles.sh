@@ -19,8 +19,9 @@ def pmc(name, ctr):
     f = glob.glob(O + "/%s/*/*counter_collection.csv" % name)[0]
     item, user = [], []
     for r in csv.DictReader(open(f)):
-        if "sweep_dma_kernel" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
-            (item if int(r["Grid_Size"]) // 64 <= 100000 else user).append(float(r["Counter_Value"]))
+        # one workgroup per row: the item sweep has 1e5 of them (single waves or wave pairs), the user sweep 1e6
+        if "mf::sweep_" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+            (item if int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1) <= 100000 else user).append(float(r["Counter_Value"]))
     return item, user
 stats()
 fi, fu = pmc("pmc_fetch", "FETCH_SIZE"); wi, wu = pmc("pmc_write", "WRITE_SIZE")
