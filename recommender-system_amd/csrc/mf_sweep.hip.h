@@ -312,13 +312,16 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 					if (rr < RPI && piece < PP && n < cnt)
 						__builtin_amdgcn_global_load_lds((mf_gvoid *) src, (mf_lvoid *) (tile + n0 * S), 16, 0, 0);
 				}
-			} else if constexpr (PF > 0 && NP == 1) {
+			} else if constexpr (PF > 0 && (NP == 1 || KT == 256)) {
 				// Lean issue (a wave walking a long row alone is bound by its own instruction stream, ~17 instructions per
 				// gathered row in the loop below): every lane forms the address of ITS entry's row once per chunk (one
 				// 64-bit multiply-add per chunk instead of four scalar multiplies per row); per row two v_readlane give the
 				// row base as a scalar pair and the transfer takes it as its scalar address with the lane's 16-byte offset
 				// as the vector part.  The asm opens with s_nop 4: an SGPR written by v_readlane needs five wait states
 				// before a VMEM instruction reads it as its address, and hipcc pads nothing inside an asm statement.
+				// K = 256 (two 1-KiB instructions per row, all lanes active in both): the second one is the first with
+				// offset:1024 -- the instruction offset of an LDS-DMA load moves the LDS side as well as the global one
+				// (tools/micro/lds_dma_offset.hip), so neither M0 nor the base is touched between the two.
 				const unsigned long long rowaddr = ybase + (unsigned long long) (unsigned) my_idx * (unsigned long long) ybytes;
 				const int alo = (int) (unsigned) rowaddr, ahi = (int) (unsigned) (rowaddr >> 32);
 				const unsigned tile_lds = (unsigned) (unsigned long long) (__attribute__((address_space(3))) char *) tile;
@@ -332,20 +335,35 @@ __global__ void __launch_bounds__(kWave) sweep_dma_kernel(SweepArgs a)
 					if (lane < P) {
 #pragma unroll
 						for (int u = 0; u < 4; ++u)
-							asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0"
-							             :
-							             : "s"(b[u]), "s"(tile_lds + (unsigned) ((n + u) * S)), "v"(voff)
-							             : "memory");
+							if constexpr (NP == 2)
+								asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0\n\t"
+								             "global_load_lds_dwordx4 %2, %0 offset:1024"
+								             :
+								             : "s"(b[u]), "s"(tile_lds + (unsigned) ((n + u) * S)), "v"(voff)
+								             : "memory");
+							else
+								asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0"
+								             :
+								             : "s"(b[u]), "s"(tile_lds + (unsigned) ((n + u) * S)), "v"(voff)
+								             : "memory");
 					}
 				}
 				for (; n < cnt; ++n) {
 					const unsigned long long b = ((unsigned long long) (unsigned) __builtin_amdgcn_readlane(ahi, n) << 32) |
 					                             (unsigned long long) (unsigned) __builtin_amdgcn_readlane(alo, n);
-					if (lane < P)
-						asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0"
-						             :
-						             : "s"(b), "s"(tile_lds + (unsigned) (n * S)), "v"(voff)
-						             : "memory");
+					if (lane < P) {
+						if constexpr (NP == 2)
+							asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0\n\t"
+							             "global_load_lds_dwordx4 %2, %0 offset:1024"
+							             :
+							             : "s"(b), "s"(tile_lds + (unsigned) (n * S)), "v"(voff)
+							             : "memory");
+						else
+							asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0"
+							             :
+							             : "s"(b), "s"(tile_lds + (unsigned) (n * S)), "v"(voff)
+							             : "memory");
+					}
 				}
 				// hipcc knows nothing of these transfers: the barrier below would not wait for them
 				MF_STAMP(t_s1);
