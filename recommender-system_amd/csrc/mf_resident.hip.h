@@ -11,7 +11,8 @@
 // A wave owns a run of CONSECUTIVE rows of its side: their records are one contiguous stretch of the record array and
 // their row pointers and seeds X_old are contiguous too, so everything the wave needs is addressed from the workgroup's
 // descriptor alone -- two memory latencies from launch to the first add, however many rows follow.  The stretch is
-// streamed in chunks of 64 records (prefetched three chunks ahead), 64 / SW entries per step: lane (g, c) forms the
+// streamed in chunks of 64 records (prefetched ahead in four registers; two chunks per fill of the step pipeline), 64 / SW
+// entries per step: lane (g, c) forms the
 // product of entry step + g for column c and parks it in LDS; then every lane adds the step's products for its column
 // in entry order, closing a row (store X_new, take the next row's seed) wherever its last entry falls.  Same rounded
 // products, same order of adds as matFact.c:41-53: bit-identical.  The chain of dependent adds (10 cycles each) is the
@@ -20,12 +21,15 @@
 #include "mf_common.hip.h"
 #include <type_traits>
 #include "mf_stream.hip.h"
+#ifndef MF_ES_ABLATE
+#define MF_ES_ABLATE 0   // diagnostic builds only (results wrong, timing valid): 1 no read-back, 2 no y gather, 3 no add chain
+#endif
 
 namespace mf {
 
 constexpr int kResidentWaves = 8;
 constexpr int kResidentThreads = kResidentWaves * kWave;
-constexpr int kResidentWaveLds = 3584;    // per wave: 64 + 3 x 32 records (padding of three steps at SW = 2) + 2 x 64 products
+constexpr int kResidentWaveLds = 4608;    // per wave: 128 + 3 x 32 records (padding of three steps at SW = 2) + 2 x 64 products
 constexpr int kResidentRows = 63;          // rows a wave owns at most: its row pointers sit in one register
 constexpr int kResidentCopyPieces = 20;   // 16-byte pieces of the Y slice a thread copies per round (20 x 512 x 16 B = 160 KB)
 
@@ -118,8 +122,8 @@ __global__ void __launch_bounds__(kResidentThreads) stream_resident_kernel(Slice
 			}
 		}
 	}
-	recbuf[64 + lane] = StreamRec{0, 0, 0.0};   // padding behind the chunk (read three steps ahead, never used)
-	if (lane < 32) recbuf[128 + lane] = StreamRec{0, 0, 0.0};
+	recbuf[128 + lane] = StreamRec{0, 0, 0.0};   // padding behind the chunk pair (read three steps ahead, never used)
+	if (lane < 32) recbuf[192 + lane] = StreamRec{0, 0, 0.0};
 	__syncthreads();
 #ifdef MF_STAMPS
 	const unsigned long long st_clk1 = __builtin_amdgcn_s_memtime();
@@ -174,10 +178,14 @@ __global__ void __launch_bounds__(kResidentThreads) stream_resident_kernel(Slice
 	// Records past the end of the chunk are stored with idx = 0 (a valid row of the slice) and recbuf carries 3 G
 	// records of padding, so the steps need neither clamps nor validity selects; runs of steps that lie inside the
 	// current row go through a loop without any row bookkeeping.
-	auto process = [&](StreamRec chunk, int c0) {
-		const int cnt = min(64, ee - c0), nsteps = (cnt + G - 1) / G;
+	// (TWO chunks per call: the pipeline is filled once per 128 records -- five dependent LDS round trips, ~700 cycles,
+	// which at one chunk per call were a third of a long run's time: tools/es_stamps.py)
+	auto process = [&](StreamRec chunk, StreamRec chunk_b, int c0) {
+		const int cnt = min(128, ee - c0), nsteps = (cnt + G - 1) / G;
 		if (lane >= cnt) chunk.idx = 0;
+		if (lane + 64 >= cnt) chunk_b.idx = 0;
 		recbuf[lane] = chunk;
+		recbuf[64 + lane] = chunk_b;
 		__builtin_amdgcn_wave_barrier();
 		StreamRec my1 = recbuf[g];                                   // step 0
 		prod[lane] = my1.err * ys[(size_t) my1.idx * SW + c];
@@ -196,15 +204,28 @@ __global__ void __launch_bounds__(kResidentThreads) stream_resident_kernel(Slice
 			constexpr int PAR = decltype(par_c)::value;
 			const int s0 = sidx * G;
 			const StreamRec my3 = recbuf[s0 + 3 * G + g];            // records of step sidx + 3 (padding past the chunk)
+#if MF_ES_ABLATE == 2
+			const double y2 = (double) my2.idx;                      // ablation: no gather of y from the LDS slice
+#else
 			const double y2 = ys[(size_t) my2.idx * SW + c];         // y of step sidx + 2
+#endif
 			prod[(PAR ^ 1) * kWave + lane] = my1.err * y1;           // products of step sidx + 1 ...
 			// ... back into registers (every lane group reads them: masking the read-back to the one group that stores
 			// the row was measured 6 % slower -- the LDS cost of an instruction does not shrink with its active lanes)
+#if MF_ES_ABLATE == 1
+#pragma unroll
+			for (int u = 0; u < G; ++u) pr[PAR ^ 1][u] = my1.err * (double) u;   // ablation: no read-back of the products
+#else
 #pragma unroll
 			for (int u = 0; u < G; ++u) pr[PAR ^ 1][u] = prod[(PAR ^ 1) * kWave + u * SW + c];
+#endif
 			if (inside) {
+#if MF_ES_ABLATE == 3
+				acc = acc + ((pr[PAR][0] + pr[PAR][1]) + (pr[PAR][G - 2] + pr[PAR][G - 1]));   // ablation: no chain of G dependent adds
+#else
 #pragma unroll
 				for (int u = 0; u < G; ++u) acc = acc + pr[PAR][u];
+#endif
 			} else {
 				const int m = min(G, cnt - s0), pos0 = c0 + s0;
 #pragma unroll
@@ -243,16 +264,14 @@ __global__ void __launch_bounds__(kResidentThreads) stream_resident_kernel(Slice
 			}
 		}
 	};
-	// four chunks per trip, each register refilled right after its chunk is consumed: no register is ever copied, so
-	// a chunk is waited for with exactly three younger loads in flight (unconditional loads: hipcc counts them)
+	// four chunks per trip, two per call, each register pair refilled right after its chunks are consumed: no register is ever
+	// copied, so a pair is waited for with exactly two younger loads in flight (unconditional loads: hipcc counts them)
 	for (int c0 = eb; c0 < ee; c0 += 256) {
-		process(r0, c0);
+		process(r0, r1, c0);
 		r0 = ld(c0 + 256);
-		if (c0 + 64 < ee) process(r1, c0 + 64);
 		r1 = ld(c0 + 320);
-		if (c0 + 128 < ee) process(r2, c0 + 128);
+		if (c0 + 128 < ee) process(r2, r3, c0 + 128);
 		r2 = ld(c0 + 384);
-		if (c0 + 192 < ee) process(r3, c0 + 192);
 		r3 = ld(c0 + 448);
 	}
 	// trailing rows without entries (and the last row when the stretch is empty)
