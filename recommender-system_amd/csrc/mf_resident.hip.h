@@ -52,8 +52,9 @@ struct SliceArgs {
 #ifdef MF_STAMPS
 // diagnostic build only (tools/es_stamps.py): per workgroup and wave -- [0] s_memrealtime at entry (100 MHz), [1] shader
 // cycles until the slice is in LDS (after the barrier), [2] shader cycles until the wave's last row is stored, [3]
-// s_memrealtime at exit, [4] entries of the wave, [5] rows of the wave
-__device__ unsigned long long mf_es_stamp_buf[512 * kResidentWaves * 6];
+// s_memrealtime at exit, [4] entries of the wave, [5] rows of the wave, [6] shader cycles in pipeline fills, [7] in runs of
+// steps inside a row, [8] those steps, [9] cycles in steps with row bookkeeping, [10] those steps, [11] fills
+__device__ unsigned long long mf_es_stamp_buf[512 * kResidentWaves * 12];
 #endif
 
 template <int SW>
@@ -126,10 +127,12 @@ __global__ void __launch_bounds__(kResidentThreads) stream_resident_kernel(Slice
 	if (lane < 32) recbuf[192 + lane] = StreamRec{0, 0, 0.0};
 	__syncthreads();
 #ifdef MF_STAMPS
+	unsigned long long st_fill = 0, st_in = 0, st_nin = 0, st_edge = 0, st_nedge = 0, st_nfill = 0;
 	const unsigned long long st_clk1 = __builtin_amdgcn_s_memtime();
 	auto stamp_out = [&]() {
 		if (lane == 0 && blockIdx.x < 512) {
-			unsigned long long *o = mf_es_stamp_buf + ((size_t) blockIdx.x * kResidentWaves + wave) * 6;
+			unsigned long long *o = mf_es_stamp_buf + ((size_t) blockIdx.x * kResidentWaves + wave) * 12;
+			o[6] = st_fill; o[7] = st_in; o[8] = st_nin; o[9] = st_edge; o[10] = st_nedge; o[11] = st_nfill;
 			o[0] = st_real0;
 			o[1] = st_clk1 - st_clk0;
 			o[2] = __builtin_amdgcn_s_memtime() - st_clk0;
@@ -182,6 +185,9 @@ __global__ void __launch_bounds__(kResidentThreads) stream_resident_kernel(Slice
 	// which at one chunk per call were a third of a long run's time: tools/es_stamps.py)
 	auto process = [&](StreamRec chunk, StreamRec chunk_b, int c0) {
 		const int cnt = min(128, ee - c0), nsteps = (cnt + G - 1) / G;
+#ifdef MF_STAMPS
+		const unsigned long long st_p0 = __builtin_amdgcn_s_memtime();
+#endif
 		if (lane >= cnt) chunk.idx = 0;
 		if (lane + 64 >= cnt) chunk_b.idx = 0;
 		recbuf[lane] = chunk;
@@ -200,6 +206,11 @@ __global__ void __launch_bounds__(kResidentThreads) stream_resident_kernel(Slice
 #pragma unroll
 		for (int u = 0; u < G; ++u) pr[0][u] = prod[u * SW + c];
 		int sidx = 0;
+#ifdef MF_STAMPS
+		asm volatile("" : "+v"(pr[0][0]));
+		st_fill += __builtin_amdgcn_s_memtime() - st_p0;
+		++st_nfill;
+#endif
 		auto step = [&](auto par_c, bool inside) {
 			constexpr int PAR = decltype(par_c)::value;
 			const int s0 = sidx * G;
@@ -246,6 +257,10 @@ __global__ void __launch_bounds__(kResidentThreads) stream_resident_kernel(Slice
 		while (sidx < nsteps) {
 			// full steps from here that end before the current row does: no row bookkeeping in their loop
 			int nf = min((cnt - sidx * G) / G, (row_end - 1 - (c0 + sidx * G)) / G);
+#ifdef MF_STAMPS
+			const unsigned long long st_r0 = __builtin_amdgcn_s_memtime();
+			const int st_s0 = sidx;
+#endif
 			if ((sidx & 1) && nf > 0) {
 				step(P1{}, true);
 				--nf;
@@ -256,11 +271,20 @@ __global__ void __launch_bounds__(kResidentThreads) stream_resident_kernel(Slice
 					step(P1{}, true);
 				}
 			if (nf > 0) step(P0{}, true);
+#ifdef MF_STAMPS
+			const unsigned long long st_r1 = __builtin_amdgcn_s_memtime();
+			st_in += st_r1 - st_r0;
+			st_nin += (unsigned long long) (sidx - st_s0);
+#endif
 			if (sidx < nsteps) {
 				if (sidx & 1)
 					step(P1{}, false);
 				else
 					step(P0{}, false);
+#ifdef MF_STAMPS
+				st_edge += __builtin_amdgcn_s_memtime() - st_r1;
+				++st_nedge;
+#endif
 			}
 		}
 	};

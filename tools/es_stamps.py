@@ -15,12 +15,12 @@ print(plan.describe())
 plan.upload(L, R)
 plan.iterate(50); plan.synchronize()
 lib = c.hip()
-NW = 512 * 8 * 6
+NW = 512 * 8 * 12
 buf = (C.c_ulonglong * NW)()
 for rep in range(3):
     plan.iterate(1); plan.synchronize()
     lib.mf_debug_read_es_stamps(buf, NW)
-    a = np.array(buf[:], dtype=np.uint64).reshape(512, 8, 6).astype(np.float64)
+    a = np.array(buf[:], dtype=np.uint64).reshape(512, 8, 12).astype(np.float64)
     used = a[:, :, 3] > 0
     wg_used = used.any(axis=1)
     t0 = a[:, :, 0][used].min()
@@ -37,6 +37,13 @@ for rep in range(3):
     for wg, w in order:
         print("   wg %3d wave %d: entries %5d rows %3d  copy %6.0f cycles  stream %6.0f cycles = %.1f per entry  entry %.2f us exit %.2f us" % (
             wg, w, a[wg, w, 4], a[wg, w, 5], a[wg, w, 1], dur[wg, w], dur[wg, w] / max(a[wg, w, 4], 1), ent[wg, w], ext[wg, w]))
+    for wg, w in order[:3]:
+        f, i, ni, e, ne, nf = a[wg, w, 6:12]
+        print("      wg %3d wave %d: %d pipeline fills %.0f cycles each | %d steps inside rows %.0f cycles each | %d steps with row bookkeeping %.0f cycles each "
+              "| accounted %.0f of %.0f cycles (the clocks themselves drain the LDS queue)" % (wg, w, nf, f / max(nf, 1), ni, i / max(ni, 1), ne, e / max(ne, 1), f + i + e, dur[wg, w]))
+    tot = a[:, :, 6:12][act].sum(axis=0)
+    print("   all waves: fills %.0f cycles each (%.0f %% of the accounted cycles), steps inside rows %.0f each (%.0f %%), steps with row bookkeeping %.0f each (%.0f %%)" % (
+        tot[0] / tot[5], 100 * tot[0] / (tot[0] + tot[1] + tot[3]), tot[1] / max(tot[2], 1), 100 * tot[1] / (tot[0] + tot[1] + tot[3]), tot[3] / max(tot[4], 1), 100 * tot[3] / (tot[0] + tot[1] + tot[3])))
     cyc_per_entry = ((a[:, :, 2] - a[:, :, 1])[act] / np.maximum(a[:, :, 4][act], 1))
     print("   cycles per entry over the waves: median %.1f, 10th-90th percentile %.1f-%.1f; entries per wave: mean %.0f max %.0f" % (
         np.median(cyc_per_entry), np.percentile(cyc_per_entry, 10), np.percentile(cyc_per_entry, 90), a[:, :, 4][act].mean(), a[:, :, 4][act].max()))
