@@ -722,11 +722,12 @@ int plan_es_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vector
 			std::vector<int> cut(1, 0);
 			{
 				const int target_runs = per * aw;
-				const double total_cost = (double) pt[(size_t) nrows] + 16.0 * nrows;
+				const double row_cost = p->cfg.es_row_cost > 0 ? (double) p->cfg.es_row_cost : 16.0;   // entries a row end is worth
+				const double total_cost = (double) pt[(size_t) nrows] + row_cost * nrows;
 				double acc_cost = 0, done = 0;
 				int in_run = 0;
 				for (int r = 0; r < nrows; ++r) {
-					acc_cost += (pt[(size_t) r + 1] - pt[(size_t) r]) + 16.0;
+					acc_cost += (pt[(size_t) r + 1] - pt[(size_t) r]) + row_cost;
 					++in_run;
 					const int left = target_runs - (int) cut.size();
 					const bool share = left > 0 && acc_cost >= (total_cost - done) / (left + 1);
