@@ -97,11 +97,18 @@ int choose_sweep(mf_plan *p)
 		// paid per chunk -- a lone 5993-entry row: 0.526 ms at 16, 0.332 at 32; cfg3 power-law 0.311 / 0.268 / 0.314 at 24 / 32 / 40
 		int npr = p->cfg.pair_nch > 0 ? p->cfg.pair_nch : 32;
 		if (p->cfg.sweep_nch) npr = p->cfg.sweep_nch;
-		while (npr > 1 && head + 2 * (size_t) npr * row_bytes > kLdsPerCu / 2) --npr;
+		const bool trio = p->sweep.trio && p->cfg.sweep_trio;   // MF_SWEEP_TRIO: loader / phase A / phase B waves, three tiles
+		const size_t tiles = trio ? 3 : 2, extra = trio ? 1024 : 0;
+		while (npr > 1 && head + extra + tiles * (size_t) npr * row_bytes > kLdsPerCu / 2) --npr;
 		p->nch_pair = npr;
-		p->lds_bytes_pair = head + 2 * (size_t) npr * row_bytes;
+		p->lds_bytes_pair = head + extra + tiles * (size_t) npr * row_bytes;
 		p->pair_loaders = p->cfg.pair_loaders == 2 && p->sweep.pair2 ? 2 : 1;
 		if (p->pair_loaders == 2) p->sweep.pair = p->sweep.pair2;
+		p->pair_waves = p->pair_loaders + 1;
+		if (trio) {
+			p->sweep.pair = p->sweep.trio;
+			p->pair_waves = 3;
+		}
 		MF_HIP(raise_lds_limit((const void *) p->sweep.pair, p->lds_bytes_pair));
 	}
 	// double-buffered form (few rows per CU: the wave hides its own gather): two tiles of nch_db rows
@@ -188,7 +195,7 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 	const int kPfRows = p->cfg.pf_rows > 0 ? p->cfg.pf_rows : (p->K > 128 ? INT_MAX : 262144);
 	const SweepFn single = p->sweep.pf && p->n_short[kind] <= kPfRows && a.nrows <= kPfRows ? p->sweep.pf : p->sweep.fn;
 	const SweepFn fn = coop ? p->sweep.coop : db ? p->sweep.db : pair ? p->sweep.pair : single;
-	const int block = coop ? mf::kCoopWaves * mf::kWave : pair ? (p->pair_loaders + 1) * mf::kWave : mf::kWave;
+	const int block = coop ? mf::kCoopWaves * mf::kWave : pair ? p->pair_waves * mf::kWave : mf::kWave;
 	const int grid = std::min(a.nrows, 1 << 20);
 	TimedLaunch t{};
 	if (p->timing) {
@@ -271,7 +278,7 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 			                       dim3(mf::kCoopWaves * mf::kWave), args, p->lds_bytes_coop, p->stream));
 		} else if (a.nrows > 0 && pair) {
 			a.nch = p->nch_pair;
-			MF_HIP(hipLaunchKernel((const void *) p->sweep.pair, dim3(std::min(a.nrows, 1 << 20)), dim3((p->pair_loaders + 1) * mf::kWave), args,
+			MF_HIP(hipLaunchKernel((const void *) p->sweep.pair, dim3(std::min(a.nrows, 1 << 20)), dim3(p->pair_waves * mf::kWave), args,
 			                       p->lds_bytes_pair, p->stream));
 		} else if (a.nrows > 0 && db) {
 			a.nch = p->nch_db;

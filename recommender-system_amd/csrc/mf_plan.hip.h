@@ -46,6 +46,7 @@ struct SweepVariant {
 	SweepFn pf;     // accumulate form with the LDS reads of phases A / B kept in flight (compile-time-K DMA variants)
 	SweepFn pair;   // wave-pair form (loader + compute) for launches that end on long rows (64 <= K <= 128, compile-time K)
 	SweepFn pair2;  // ... with two loader waves
+	SweepFn trio = nullptr;   // ... with the compute wave split into a phase-A and a phase-B wave (three waves per row)
 };
 
 template <int KT, int KP>
@@ -62,6 +63,14 @@ constexpr SweepFn pair_fn()
 	else
 		return nullptr;
 }
+template <int KT>
+constexpr SweepFn trio_fn()
+{
+	if constexpr (mf::DmaGeom<KT>::kPasses == 1 && (mf::DmaGeom<KT>::kPieces | 1) > 32)
+		return mf::sweep_trio_kernel<KT>;
+	else
+		return nullptr;
+}
 
 template <int KT>
 constexpr SweepVariant dma_variant()
@@ -73,9 +82,10 @@ constexpr SweepVariant dma_variant()
 	                    mf::sweep_db_kernel<KT, mf::DmaGeom<KT>::kPasses>,
 	                    mf::sweep_dma_kernel<KT, mf::DmaGeom<KT>::kPasses, mf::kSweepAccumulate, 8>, pair_fn<KT, 1>(),
 #ifdef MF_EXPERIMENTS
-	                    pair_fn<KT, 2>()   // two loader waves: measured within noise of one (the compute wave is the bound)
+	                    pair_fn<KT, 2>(),   // two loader waves: measured within noise of one (the compute wave is the bound)
+	                    trio_fn<KT>()       // loader / phase-A / phase-B waves: faster only where ONE row sets the sweep's time
 #else
-	                    nullptr
+	                    nullptr, nullptr
 #endif
 	};
 }
@@ -179,6 +189,7 @@ struct mf_plan {
 	bool use_db[2] = {false, false};   // the sweep's single-wave launch takes the double-buffered form (plan_row_schedule)
 	bool use_pair[2] = {false, false}; // ... or the wave-pair form
 	int nch_pair = 0;
+	int pair_waves = 2;   // waves per row of the pair form in use: 2 (loader + compute), 3 with two loaders or with the trio kernel
 	int pair_loaders = 1;   // loader waves of the wave-pair form
 	size_t lds_bytes_pair = 0;
 	// mid-length rows of a skewed sweep (below the extreme threshold, far above the mean): their own launch of the

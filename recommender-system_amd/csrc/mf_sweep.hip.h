@@ -926,6 +926,156 @@ __global__ void __launch_bounds__((NL + 1) * kWave) sweep_pair_kernel(SweepArgs 
 	}
 }
 
+// Three waves per row: loader, phase A, phase B -- the pair's compute wave split in two.  A pair walks a row at
+// max(issue + landing, A + B) per chunk and is bound by A + B (clocks of a lone long row, tools/stamps.py: per 16 entries
+// issue 1430 / landing 370 / phase A 1770 / phase B 1100 cycles; phase A costs the same for 32 entries, lane = entry); with
+// the phases on separate waves, one chunk apart, the walk costs max(issue + landing, A, B).  Lockstep pipeline, ONE barrier
+// per step s: the loader fills tile s % 3 with chunk s, the A wave forms the errors of chunk s-1 (tile (s-1) % 3) and parks
+// them in ebuf[(s-1) & 1], the B wave accumulates chunk s-2 (tile (s-2) % 3, errors from ebuf[s & 1]).  The barrier that ends
+// step s says: chunk s has landed, the errors of chunk s-1 are in LDS, tile (s-2) % 3 = (s+1) % 3 is consumed.  The
+// arithmetic is that of the pair's compute wave, in the same order => same bits.
+// Measured (tools/r3_trio_ab.sh, profiles/r03/trio_ab.txt; experiments build, MF_SWEEP_TRIO=1): the side whose time IS its
+// longest row gains -- cfg3 power-law users 0.138 -> 0.121 ms -- but every throughput-bound side loses to the third tile
+// (fewer workgroups per CU): cfg3 power-law items 0.115 -> 0.151, Netflix-shape items 9.97 -> 10.48 ms, cfg4 items 11.84 ->
+// 12.68.  Not chosen by any rule; kept bit-exact and tested for the next round (a per-side choice).
+template <int KT>
+__global__ void __launch_bounds__(3 * kWave) sweep_trio_kernel(SweepArgs a)
+{
+	using G = DmaGeom<KT>;
+	static_assert(G::kPasses == 1 && (G::kPieces | 1) > 32, "one LDS-DMA instruction per gathered row");
+	constexpr int P = G::kPieces, S = G::kStride;
+	extern __shared__ __attribute__((aligned(16))) char lds[];
+	double2 *xs = reinterpret_cast<double2 *>(lds);
+	double *ebuf = reinterpret_cast<double *>(lds + G::kXsBytes);   // 2 x 64 errors
+	char *tile0 = lds + G::kXsBytes + 1024;
+	const int nch = a.nch;
+	const int tile_bytes = nch * S;
+	const unsigned tile0_lds = (unsigned) (unsigned long long) (__attribute__((address_space(3))) char *) tile0;
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));   // scalar: the roles never share a branch mask
+	const unsigned voff = (unsigned) lane * 16u;
+	const unsigned long long ybase = (unsigned long long) a.Y_old;
+	const unsigned long long ybytes = (unsigned long long) a.ldy * 8ull;
+
+	for (int it = blockIdx.x; it < a.nrows; it += gridDim.x) {
+		const int r = a.rowlist ? a.rowlist[it] : it;
+		const int beg = a.ptr[r], end = a.ptr[r + 1];
+		const int nchunks = (end - beg + nch - 1) / nch;
+		const bool long_row = a.prio_len > 0 && end - beg >= a.prio_len;
+		if (long_row)
+			__builtin_amdgcn_s_setprio(3);
+		else if (wave == 0)
+			__builtin_amdgcn_s_setprio(1);   // its few instructions gate the two other waves
+		else
+			__builtin_amdgcn_s_setprio(0);
+		if (wave == 0) {
+			// ---------------- loader: chunk s -> tile s % 3
+			int nx_idx = 0;
+			if (beg + lane < min(end, beg + nch)) nx_idx = a.idx[beg + lane];
+			int ti = 0;
+			for (int s = 0; s < nchunks + 2; ++s) {
+				if (s < nchunks) {
+					const int c = beg + s * nch;
+					const int cnt = min(nch, end - c);
+					int my_idx = nx_idx;
+					asm volatile("" : "+v"(my_idx));   // hipcc's wait for this load stays here, outside the loops below
+					nx_idx = 0;
+					if (c + nch + lane < min(end, c + 2 * nch)) nx_idx = a.idx[c + nch + lane];
+					const unsigned long long rowaddr = ybase + (unsigned long long) (unsigned) my_idx * ybytes;
+					const int alo = (int) (unsigned) rowaddr, ahi = (int) (unsigned) (rowaddr >> 32);
+					const unsigned tb = tile0_lds + (unsigned) (ti * tile_bytes);
+					int n = 0;
+					for (; n + 4 <= cnt; n += 4) {
+						unsigned long long b[4];
+#pragma unroll
+						for (int u = 0; u < 4; ++u)
+							b[u] = ((unsigned long long) (unsigned) __builtin_amdgcn_readlane(ahi, n + u) << 32) |
+							       (unsigned long long) (unsigned) __builtin_amdgcn_readlane(alo, n + u);
+						if (lane < P) {
+#pragma unroll
+							for (int u = 0; u < 4; ++u)
+								asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0"
+								             :
+								             : "s"(b[u]), "s"(tb + (unsigned) ((n + u) * S)), "v"(voff)
+								             : "memory");
+						}
+					}
+					for (; n < cnt; ++n) {
+						const unsigned long long b = ((unsigned long long) (unsigned) __builtin_amdgcn_readlane(ahi, n) << 32) |
+						                             (unsigned long long) (unsigned) __builtin_amdgcn_readlane(alo, n);
+						if (lane < P)
+							asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0"
+							             :
+							             : "s"(b), "s"(tb + (unsigned) (n * S)), "v"(voff)
+							             : "memory");
+					}
+				}
+				// landed (this also retires the index load of the next chunk, issued in front of the transfers)
+				asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+				ti = ti == 2 ? 0 : ti + 1;
+			}
+		} else if (wave == 1) {
+			// ---------------- phase A of chunk s - 1 at step s: the errors, parked in ebuf[(s - 1) & 1]
+			const double2 *__restrict__ xrow2 = reinterpret_cast<const double2 *>(a.X_old + (size_t) r * a.ldx);
+			if (lane < P) xs[lane] = xrow2[lane];
+			double nx_val = 0.0;
+			if (beg + lane < min(end, beg + nch)) nx_val = a.val[beg + lane];
+			int ti = 0;   // tile of chunk s - 1
+			for (int s = 0; s < nchunks + 2; ++s) {
+				if (s >= 1 && s <= nchunks) {
+					const int c = beg + (s - 1) * nch;
+					const double my_val = nx_val;
+					nx_val = 0.0;
+					if (c + nch + lane < min(end, c + 2 * nch)) nx_val = a.val[c + nch + lane];
+					const char *tile = tile0 + ti * tile_bytes;
+					const double2 *t2 = reinterpret_cast<const double2 *>(tile + (lane < nch ? lane : 0) * S);
+					const double dot = phase_a_dot_ahead<KT / 2, 8>(t2, xs);
+					ebuf[((s - 1) & 1) * kWave + lane] = a.c2 * (my_val - dot);
+					ti = ti == 2 ? 0 : ti + 1;
+				}
+				asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(nx_val)::"memory");
+			}
+		} else {
+			// ---------------- phase B of chunk s - 2 at step s
+			const double2 *__restrict__ xrow2 = reinterpret_cast<const double2 *>(a.X_old + (size_t) r * a.ldx);
+			double2 acc = make_double2(0.0, 0.0);
+			if (lane < P && a.seed) acc = xrow2[lane];
+			const unsigned boff = (unsigned) (lane < P ? lane : 0) * 16u;   // lanes beyond the row re-read piece 0: no branch masks
+			int ti = 0;   // tile of chunk s - 2
+			for (int s = 0; s < nchunks + 2; ++s) {
+				if (s >= 2) {
+					const int c = beg + (s - 2) * nch;
+					const int cnt = min(nch, end - c);
+					const double e = ebuf[(s & 1) * kWave + lane];
+					const char *tb = tile0 + ti * tile_bytes + boff;
+					int n = 0;
+					for (; n + 16 <= cnt; n += 16) {
+						double2 t[16];
+#pragma unroll
+						for (int u = 0; u < 16; ++u) t[u] = *reinterpret_cast<const double2 *>(tb + (n + u) * S);
+						asm volatile("" ::: "memory");
+#pragma unroll
+						for (int u = 0; u < 16; ++u) {
+							const double en = readlane_f64(e, n + u);
+							acc.x = acc.x + en * t[u].x;
+							acc.y = acc.y + en * t[u].y;
+						}
+					}
+					for (; n < cnt; ++n) {
+						const double en = readlane_f64(e, n);
+						const double2 t = *reinterpret_cast<const double2 *>(tb + n * S);
+						acc.x = acc.x + en * t.x;
+						acc.y = acc.y + en * t.y;
+					}
+					ti = ti == 2 ? 0 : ti + 1;
+				}
+				asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(acc.x), "+v"(acc.y)::"memory");
+			}
+			if (lane < P) reinterpret_cast<double2 *>(a.X_new + (size_t) r * a.ldx)[lane] = acc;
+		}
+	}
+}
+
 // Ordered sum of the scaled rows of one extreme row: X_new[r][k] = (...((seed + p_0[k]) + p_1[k]) + ...), the
 // serial accumulation order.  One wave per (row, 8-column slice).  The slice is contiguous over the entries (64 B
 // each), so ONE LDS-DMA instruction brings a block of 16 consecutive entries (1 KiB) into a slot of an LDS ring and the

@@ -306,7 +306,7 @@ def test_switches_are_read_once_per_plan_and_experiments_are_not_in_the_shipped_
     assert "config{MF_SWEEP_NCH=7}" in later.describe() and " nch=7 " in later.describe(), later.describe()
     monkeypatch.delenv("MF_SWEEP_NCH")
     for k, v in (("MF_SWEEP_SEG", "32"), ("MF_SWEEP_PNCH", "8"), ("MF_ES_NCH", "8"), ("MF_SWEEP_FEW", "1"), ("MF_SWEEP_PF", "0"),
-                 ("MF_ES_ACTIVE", "4"), ("MF_ES_ROW_COST", "40"), ("MF_SWEEP_PAIR_I", "1"), ("MF_SWEEP_PF_ROWS", "5"), ("MF_RECOMMEND_WIDE", "1")):
+                 ("MF_ES_ACTIVE", "4"), ("MF_ES_ROW_COST", "40"), ("MF_SWEEP_PAIR_I", "1"), ("MF_SWEEP_TRIO", "1"), ("MF_SWEEP_PF_ROWS", "5"), ("MF_RECOMMEND_WIDE", "1")):
         monkeypatch.setenv(k, v)                        # experiments: not compiled into the shipped library
     exp = capi.Plan(120, 90, 100, 0.01, d["row"], d["col"], d["val"])
     assert exp.describe() == plain.describe(), (exp.describe(), plain.describe())
