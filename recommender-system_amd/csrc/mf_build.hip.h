@@ -624,6 +624,12 @@ int plan_row_schedule(mf_plan *p, const std::vector<int> &rptr, const std::vecto
 		p->use_db[kind] = p->sweep.db && !p->coop_all[kind] && !p->rest_coop && launch_rows > 0 &&
 		                  (p->cfg.sweep_db == 1 || (p->cfg.sweep_db < 0 && launch_rows <= limit));
 		p->use_pair[kind] = !p->coop_all[kind] && !p->rest_coop && !p->use_db[kind] && launch_rows > 0 && pair_wanted(p, kind);
+		// Trios (loader / phase-A / phase-B waves, mf_sweep.hip.h): experiments build only, MF_SWEEP_TRIO=1 (every side that
+		// runs pairs) or MF_SWEEP_TRIO_U=1 (the user side alone).  No rule chooses them: on the one side they were meant for --
+		// cfg3 power-law users, not split, longest row 2324 entries = 128 us of walk against 112 us of bytes -- the trio alone
+		// is slower than the pair (0.1447 vs 0.1378 ms with the items on pairs; the 0.121 of the all-trio run was the item
+		// side's ordered sums no longer overlapping the user sweep), and every throughput-bound side loses to the third tile.
+		p->use_trio[kind] = p->use_pair[kind] && p->sweep.trio && (p->cfg.sweep_trio == 1 || (kind == 1 && p->cfg.sweep_trio == 2));
 	}
 	// ---- a sweep of a few thousand rows is a handful of rounds of workgroups: in index order its tail is whatever
 	// long rows happen to start last.  Longest first (workgroups are dispatched in list order) the tail is made of the

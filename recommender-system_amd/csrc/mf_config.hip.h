@@ -50,7 +50,7 @@ struct mf_config {
 	bool no_defer = false;            // MF_SWEEP_NO_DEFER
 	bool nosort = false;              // MF_SWEEP_NOSORT
 	bool rest_coop = false;           // MF_SWEEP_REST=coop
-	bool sweep_trio = false;          // MF_SWEEP_TRIO=1: the pair form's compute wave split into a phase-A and a phase-B wave
+	int sweep_trio = 0;               // MF_SWEEP_TRIO=1 / MF_SWEEP_TRIO_U=1: the pair form's compute wave split into a phase-A and a phase-B wave wherever pairs run / on the user side
 	int sweep_pair_kind[2] = {-1, -1};  // MF_SWEEP_PAIR_I / MF_SWEEP_PAIR_U = 0|1: the wave-pair form of the item / user sweep alone
 	int es_row_cost = 0;              // MF_ES_ROW_COST: entries a row end counts for when the streams launch cuts its runs (0: rule)
 	int es_active = 0;                // MF_ES_ACTIVE=1..8: waves per workgroup of the streams launch that own rows (0: rule)
@@ -116,7 +116,8 @@ struct mf_config {
 		if ((v = getenv("MF_ES_NCH"))) c.es_nch = atoi(v);
 		if ((v = getenv("MF_ES_ACTIVE"))) c.es_active = atoi(v);
 		if ((v = getenv("MF_ES_ROW_COST"))) c.es_row_cost = atoi(v);
-		if ((v = getenv("MF_SWEEP_TRIO"))) c.sweep_trio = !is0(v);
+		if ((v = getenv("MF_SWEEP_TRIO"))) c.sweep_trio = is0(v) ? 0 : 1;
+		if ((v = getenv("MF_SWEEP_TRIO_U")) && !is0(v)) c.sweep_trio = 2;
 		if ((v = getenv("MF_SWEEP_PAIR_I"))) c.sweep_pair_kind[0] = is0(v) ? 0 : 1;
 		if ((v = getenv("MF_SWEEP_PAIR_U"))) c.sweep_pair_kind[1] = is0(v) ? 0 : 1;
 		if ((v = getenv("MF_SWEEP_DB_ROWS"))) c.db_rows = atoi(v);
@@ -176,7 +177,7 @@ struct mf_config {
 		if (es_nch) add("MF_ES_NCH", std::to_string(es_nch));
 		if (es_active) add("MF_ES_ACTIVE", std::to_string(es_active));
 		if (es_row_cost) add("MF_ES_ROW_COST", std::to_string(es_row_cost));
-		if (sweep_trio) add("MF_SWEEP_TRIO", "1");
+		if (sweep_trio) add(sweep_trio == 2 ? "MF_SWEEP_TRIO_U" : "MF_SWEEP_TRIO", "1");
 		if (sweep_pair_kind[0] >= 0) add("MF_SWEEP_PAIR_I", std::to_string(sweep_pair_kind[0]));
 		if (sweep_pair_kind[1] >= 0) add("MF_SWEEP_PAIR_U", std::to_string(sweep_pair_kind[1]));
 		if (db_rows) add("MF_SWEEP_DB_ROWS", std::to_string(db_rows));

@@ -802,10 +802,10 @@ int mf_plan_describe(mf_plan *p, char *buf, int buflen)
 	int n;
 	if (p->sweep.dma)
 		n = snprintf(buf, (size_t) buflen,
-		             "sweep_dma_kernel<KT=%d,NPASS=%d> K=%d pitch=%d/%d nch=%d row_bytes=%d lds=%zu long_rows=%d/%d coop_nch=%d double_buffered=%d/%d(nch=%d) mid_rows=%d/%d(nch=%d) wave_pair=%d/%d(nch=%d)",
+		             "sweep_dma_kernel<KT=%d,NPASS=%d> K=%d pitch=%d/%d nch=%d row_bytes=%d lds=%zu long_rows=%d/%d coop_nch=%d double_buffered=%d/%d(nch=%d) mid_rows=%d/%d(nch=%d) wave_pair=%d/%d(nch=%d) trio=%d/%d",
 		             p->sweep.kt, p->sweep.kt ? (p->K / 2 + 63) / 64 : p->sweep.kpmax, p->K, p->ldl, p->ldr, p->nch, p->sweep.row_bytes,
 		             p->lds_bytes, p->n_long[0] + (p->coop_all[0] ? p->items : 0), p->n_long[1] + (p->coop_all[1] ? p->uc : 0),
-		             p->coop_all[0] || p->coop_all[1] ? p->nch_coop : 0, (int) p->use_db[0], (int) p->use_db[1], p->nch_db, p->n_mid[0], p->n_mid[1], p->nch_mid, (int) p->use_pair[0], (int) p->use_pair[1], p->nch_pair);
+		             p->coop_all[0] || p->coop_all[1] ? p->nch_coop : 0, (int) p->use_db[0], (int) p->use_db[1], p->nch_db, p->n_mid[0], p->n_mid[1], p->nch_mid, (int) p->use_pair[0], (int) p->use_pair[1], p->nch_pair, (int) p->use_trio[0], (int) p->use_trio[1]);
 	else
 		n = snprintf(buf, (size_t) buflen, "sweep_kernel<KT=%d,KPMAX=%d> K=%d nch=%d stride=%d lds=%zu",
 		             p->sweep.kt, p->sweep.kpmax, p->K, p->nch, p->stride, p->lds_bytes);

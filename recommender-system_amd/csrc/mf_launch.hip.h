@@ -97,19 +97,21 @@ int choose_sweep(mf_plan *p)
 		// paid per chunk -- a lone 5993-entry row: 0.526 ms at 16, 0.332 at 32; cfg3 power-law 0.311 / 0.268 / 0.314 at 24 / 32 / 40
 		int npr = p->cfg.pair_nch > 0 ? p->cfg.pair_nch : 32;
 		if (p->cfg.sweep_nch) npr = p->cfg.sweep_nch;
-		const bool trio = p->sweep.trio && p->cfg.sweep_trio;   // MF_SWEEP_TRIO: loader / phase A / phase B waves, three tiles
-		const size_t tiles = trio ? 3 : 2, extra = trio ? 1024 : 0;
-		while (npr > 1 && head + extra + tiles * (size_t) npr * row_bytes > kLdsPerCu / 2) --npr;
+		while (npr > 1 && head + 2 * (size_t) npr * row_bytes > kLdsPerCu / 2) --npr;
 		p->nch_pair = npr;
-		p->lds_bytes_pair = head + extra + tiles * (size_t) npr * row_bytes;
+		p->lds_bytes_pair = head + 2 * (size_t) npr * row_bytes;
 		p->pair_loaders = p->cfg.pair_loaders == 2 && p->sweep.pair2 ? 2 : 1;
 		if (p->pair_loaders == 2) p->sweep.pair = p->sweep.pair2;
 		p->pair_waves = p->pair_loaders + 1;
-		if (trio) {
-			p->sweep.pair = p->sweep.trio;
-			p->pair_waves = 3;
-		}
 		MF_HIP(raise_lds_limit((const void *) p->sweep.pair, p->lds_bytes_pair));
+		if (p->sweep.trio) {   // loader / phase-A / phase-B waves: three tiles + the errors of two chunks
+			int ntr = p->cfg.pair_nch > 0 ? p->cfg.pair_nch : 32;
+			if (p->cfg.sweep_nch) ntr = p->cfg.sweep_nch;
+			while (ntr > 1 && head + 1024 + 3 * (size_t) ntr * row_bytes > kLdsPerCu / 2) --ntr;
+			p->nch_trio = ntr;
+			p->lds_bytes_trio = head + 1024 + 3 * (size_t) ntr * row_bytes;
+			MF_HIP(raise_lds_limit((const void *) p->sweep.trio, p->lds_bytes_trio));
+		}
 	}
 	// double-buffered form (few rows per CU: the wave hides its own gather): two tiles of nch_db rows
 	if (p->sweep.db) {
@@ -182,10 +184,11 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 	const bool coop = p->coop_all[kind];
 	const bool db = !coop && p->use_db[kind];
 	const bool pair = !coop && !db && p->use_pair[kind];
+	const bool trio = pair && p->use_trio[kind] && p->sweep.trio;
 	if (few_rows) a.nch = coop ? p->nch_coop : p->nch_few;
 	if (db) a.nch = p->nch_db;
-	if (pair) a.nch = p->nch_pair;
-	const size_t lds = coop ? p->lds_bytes_coop : db ? p->lds_bytes_db : pair ? p->lds_bytes_pair : (few_rows ? p->lds_bytes_few : p->lds_bytes);
+	if (pair) a.nch = trio ? p->nch_trio : p->nch_pair;
+	const size_t lds = coop ? p->lds_bytes_coop : db ? p->lds_bytes_db : trio ? p->lds_bytes_trio : pair ? p->lds_bytes_pair : (few_rows ? p->lds_bytes_few : p->lds_bytes);
 	// Accumulate form of the single-wave launch.  Up to kPfRows rows: the form whose phases keep their LDS reads in flight
 	// and whose gather issue is lean -- what a wave walking a long row alone is bound by (cfg3 uniform 0.224 -> 0.201 ms,
 	// power-law 0.367 -> 0.350, a lone 5993-entry row 1.02 -> 0.78 ms).  Larger launches of one-pass rows (K <= 128) are
@@ -194,8 +197,8 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 	// CU do not hide, and keeping its LDS reads in flight shortens it (cfg5: 346.6 -> 327.9 ms, 0.745 -> 0.787).
 	const int kPfRows = p->cfg.pf_rows > 0 ? p->cfg.pf_rows : (p->K > 128 ? INT_MAX : 262144);
 	const SweepFn single = p->sweep.pf && p->n_short[kind] <= kPfRows && a.nrows <= kPfRows ? p->sweep.pf : p->sweep.fn;
-	const SweepFn fn = coop ? p->sweep.coop : db ? p->sweep.db : pair ? p->sweep.pair : single;
-	const int block = coop ? mf::kCoopWaves * mf::kWave : pair ? p->pair_waves * mf::kWave : mf::kWave;
+	const SweepFn fn = coop ? p->sweep.coop : db ? p->sweep.db : trio ? p->sweep.trio : pair ? p->sweep.pair : single;
+	const int block = coop ? mf::kCoopWaves * mf::kWave : trio ? 3 * mf::kWave : pair ? p->pair_waves * mf::kWave : mf::kWave;
 	const int grid = std::min(a.nrows, 1 << 20);
 	TimedLaunch t{};
 	if (p->timing) {
@@ -277,9 +280,9 @@ int launch_sweep(mf_plan *p, int kind, int seed, bool defer_join = false)
 			MF_HIP(hipLaunchKernel((const void *) p->sweep.coop, dim3(std::min(a.nrows, 1 << 20)),
 			                       dim3(mf::kCoopWaves * mf::kWave), args, p->lds_bytes_coop, p->stream));
 		} else if (a.nrows > 0 && pair) {
-			a.nch = p->nch_pair;
-			MF_HIP(hipLaunchKernel((const void *) p->sweep.pair, dim3(std::min(a.nrows, 1 << 20)), dim3(p->pair_waves * mf::kWave), args,
-			                       p->lds_bytes_pair, p->stream));
+			a.nch = trio ? p->nch_trio : p->nch_pair;
+			MF_HIP(hipLaunchKernel((const void *) (trio ? p->sweep.trio : p->sweep.pair), dim3(std::min(a.nrows, 1 << 20)),
+			                       dim3((trio ? 3 : p->pair_waves) * mf::kWave), args, trio ? p->lds_bytes_trio : p->lds_bytes_pair, p->stream));
 		} else if (a.nrows > 0 && db) {
 			a.nch = p->nch_db;
 			MF_HIP(hipLaunchKernel((const void *) p->sweep.db, dim3(std::min(a.nrows, 1 << 20)), dim3(mf::kWave), args,

@@ -83,7 +83,7 @@ constexpr SweepVariant dma_variant()
 	                    mf::sweep_dma_kernel<KT, mf::DmaGeom<KT>::kPasses, mf::kSweepAccumulate, 8>, pair_fn<KT, 1>(),
 #ifdef MF_EXPERIMENTS
 	                    pair_fn<KT, 2>(),   // two loader waves: measured within noise of one (the compute wave is the bound)
-	                    trio_fn<KT>()       // loader / phase-A / phase-B waves: faster only where ONE row sets the sweep's time
+	                    trio_fn<KT>()       // loader / phase-A / phase-B waves: measured slower wherever it was tried
 #else
 	                    nullptr, nullptr
 #endif
@@ -189,7 +189,10 @@ struct mf_plan {
 	bool use_db[2] = {false, false};   // the sweep's single-wave launch takes the double-buffered form (plan_row_schedule)
 	bool use_pair[2] = {false, false}; // ... or the wave-pair form
 	int nch_pair = 0;
-	int pair_waves = 2;   // waves per row of the pair form in use: 2 (loader + compute), 3 with two loaders or with the trio kernel
+	int pair_waves = 2;   // waves per row of the pair form in use: 2 (loader + compute), 3 with two loaders
+	bool use_trio[2] = {false, false};   // ... that side's pairs as loader / phase-A / phase-B trios (three tiles)
+	int nch_trio = 0;
+	size_t lds_bytes_trio = 0;
 	int pair_loaders = 1;   // loader waves of the wave-pair form
 	size_t lds_bytes_pair = 0;
 	// mid-length rows of a skewed sweep (below the extreme threshold, far above the mean): their own launch of the

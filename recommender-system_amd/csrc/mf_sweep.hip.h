@@ -937,7 +937,8 @@ __global__ void __launch_bounds__((NL + 1) * kWave) sweep_pair_kernel(SweepArgs 
 // Measured (tools/r3_trio_ab.sh, profiles/r03/trio_ab.txt; experiments build, MF_SWEEP_TRIO=1): the side whose time IS its
 // longest row gains -- cfg3 power-law users 0.138 -> 0.121 ms -- but every throughput-bound side loses to the third tile
 // (fewer workgroups per CU): cfg3 power-law items 0.115 -> 0.151, Netflix-shape items 9.97 -> 10.48 ms, cfg4 items 11.84 ->
-// 12.68.  Not chosen by any rule; kept bit-exact and tested for the next round (a per-side choice).
+// 12.68.  And the users' gain was the item side's ordered sums no longer overlapping the user sweep: with trios on the user
+// side ALONE (MF_SWEEP_TRIO_U=1) it is 0.1447 against 0.1378 ms.  Not chosen by any rule; experiments build only.
 template <int KT>
 __global__ void __launch_bounds__(3 * kWave) sweep_trio_kernel(SweepArgs a)
 {
